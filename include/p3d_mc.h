@@ -1,0 +1,101 @@
+/*
+ * p3d_mc.h -- C ABI of the MI355X-native marching-cubes hot path (libp3dmc.so).
+ *
+ * This is the drop-in boundary beneath Primitive3D's pybind surface.  Every entry point names the
+ * reference interface it replaces (paths are into the upstream repo lzhnb/Primitive3D):
+ *
+ *   prim3d::marching_cubes(const Tensor&, float, vector<float>, vector<float>)
+ *       src/prim3d/Utility/marching_cubes.h:14-15, marching_cubes.cu:212-305
+ *         :229-252  counters + count_vertices_faces_kernel + 2x .item()  -> p3d_mc_count + p3d_mc_read_counts
+ *         :257-298  allocations + gen_vertices/gen_faces kernels + scale/offset epilogue -> p3d_mc_emit
+ *   (the pybind module src/pybind/bindings.cpp:30 keeps its signature; it becomes a thin adapter that
+ *   allocates torch tensors between the two phases -- see INTEGRATION.md.)
+ *
+ * Conventions
+ *   - All pointers except `counts` outputs are DEVICE pointers owned by the caller; nothing is
+ *     allocated, freed or retained by the library.  No torch types cross this boundary.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All calls enqueue work on
+ *     it and return immediately, except p3d_mc_read_counts which synchronises the stream.
+ *   - Grid layout is the reference's: contiguous [rx][ry][rz], z fastest (marching_cubes.cu:20).
+ *   - Return value 0 on success, negative P3D_E* on failure; p3d_last_error() gives a thread-local
+ *     message.
+ *   - Vertex order and face order are unspecified (as in the reference, whose order is atomicAdd
+ *     arrival order, marching_cubes.cu:104,199) but deterministic for a given build and input.
+ */
+#ifndef P3D_MC_H_
+#define P3D_MC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P3D_MC_ABI_VERSION 1
+
+/* dtype of the scalar field */
+#define P3D_F32 0
+#define P3D_F16 1
+
+/* error codes */
+#define P3D_OK 0
+#define P3D_EINVAL (-1)   /* bad argument (null pointer, dims < 1, unknown dtype) */
+#define P3D_ERANGE (-2)   /* problem too large for int32 vertex ids / workspace math */
+#define P3D_EHIP (-3)     /* a HIP runtime call failed */
+#define P3D_ECAPACITY (-4) /* outputs did not fit the capacity given to p3d_mc_emit */
+
+/* Slab description for multi-GPU runs (axis-0 slabs, one halo plane).
+ * A single-GPU call uses p3d_mc_slab_whole(). */
+typedef struct p3d_mc_slab {
+    int32_t halo_last_plane; /* 1: plane rx-1 of `grid` is a halo copy of the next rank's first
+                                plane: its in-plane (axis 1/2) edges are owned by that rank, so no
+                                vertices are emitted for them and their index records are imported
+                                with p3d_mc_import_halo_records. */
+    int32_t reserved;
+    int64_t vertex_id_base;      /* added to every locally owned vertex id written into faces */
+    int64_t halo_vertex_id_base; /* added to the imported records of the halo plane */
+    int64_t x_origin;            /* global axis-0 index of local plane 0: vertex x = float(x_origin + x) + dt */
+} p3d_mc_slab;
+
+/* Bytes of device scratch p3d_mc_count / p3d_mc_emit need for an [rx,ry,rz] grid.
+ * Replaces: `vertex_grids` + `counters` (marching_cubes.cu:229-230, 257-259); 0.25 B/voxel + O(1)
+ * instead of 12 B/voxel. */
+int p3d_mc_workspace_bytes(int64_t rx, int64_t ry, int64_t rz, size_t* bytes);
+
+/* Phase 1 (replaces count_vertices_faces_kernel launch, marching_cubes.cu:242-249): classify the
+ * field against `thresh` (inside = value > thresh, strict), build the per-voxel sign bitfield and
+ * the per-unit vertex-id records in `ws`, and count vertices and triangles.  Totals stay on the
+ * device in `ws` until p3d_mc_read_counts.  `slab` may be NULL (whole grid). */
+int p3d_mc_count(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz, float thresh,
+                 const p3d_mc_slab* slab, void* ws, void* stream);
+
+/* Blocking read of the totals (replaces the two .item() calls, marching_cubes.cu:251-252).
+ * num_faces is triangles, not indices. */
+int p3d_mc_read_counts(const void* ws, int64_t* num_vertices, int64_t* num_faces, void* stream);
+
+/* Phase 2 (replaces gen_vertices_kernel, gen_faces_kernel and the epilogue, marching_cubes.cu:266-298):
+ * write vertices [V,3] f32 already mapped to the bounding box (v * scale + lower, scale as in
+ * :293-297 including the upper[2]-lower[1] term of :295) and faces [F,3] i32.  Must follow a
+ * p3d_mc_count on the same grid/ws.  cap_vertices/cap_faces are the capacities of the two buffers
+ * in elements (rows); nothing is written past them and P3D_ECAPACITY is NOT detected here (the
+ * caller compares the counts).  vertex_keys (nullable) receives per-vertex edge keys
+ * voxel_linear*3+axis (int64, debug/parity output, local slab indexing). */
+int p3d_mc_emit(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz, float thresh,
+                const float lower[3], const float upper[3], const int64_t full_res[3],
+                const p3d_mc_slab* slab, void* ws, float* vertices, int64_t cap_vertices,
+                int32_t* faces, int64_t cap_faces, int64_t* vertex_keys, void* stream);
+
+/* Multi-GPU helpers: location and size of the per-plane vertex-id records inside `ws`, so the host
+ * can ship the next rank's plane-0 records into this rank's halo plane (RCCL send/recv of
+ * `bytes_per_plane` bytes).  plane is a local axis-0 index. */
+int p3d_mc_plane_records(void* ws, int64_t rx, int64_t ry, int64_t rz, int64_t plane,
+                         void** records, size_t* bytes_per_plane);
+
+const char* p3d_last_error(void);
+int p3d_mc_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P3D_MC_H_ */

@@ -1,0 +1,80 @@
+"""In-tree builds of the two native artefacts (both land next to this file so they travel with the
+repo snapshot):
+
+  libp3dmc.so        HIP kernels + C ABI (include/p3d_mc.h), built with hipcc for gfx950
+  libPrim3D*.so      pybind adapter (csrc/bindings.cpp) over that C ABI, built with the host compiler
+                     against libtorch; module name kept from the reference (src/pybind/CMakeLists.txt:13-14)
+"""
+import os
+import subprocess
+import sys
+import sysconfig
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+ROOT = PKG.parent
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+
+def _stale(out: Path, deps) -> bool:
+    if not out.exists():
+        return True
+    t = out.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def capi_path() -> Path:
+    return PKG / "libp3dmc.so"
+
+
+def pybind_path() -> Path:
+    return PKG / ("libPrim3D" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_capi(force: bool = False, verbose: bool = False) -> Path:
+    out = capi_path()
+    deps = [CSRC / "p3d_mc.hip", CSRC / "tri_table_packed.inc", ROOT / "include" / "p3d_mc.h"]
+    if force or _stale(out, deps):
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+               # the reference epilogue is mul-then-add, never an FMA (marching_cubes.cu:298)
+               "-ffp-contract=off", "-Wall", "-Wextra",
+               str(CSRC / "p3d_mc.hip"), "-o", str(out)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return out
+
+
+def build_pybind(force: bool = False, verbose: bool = False) -> Path:
+    out = pybind_path()
+    deps = [CSRC / "bindings.cpp", ROOT / "include" / "p3d_mc.h"]
+    if force or _stale(out, deps):
+        import torch
+        from torch.utils import cpp_extension as ce
+        inc = []
+        for p in ce.include_paths():
+            inc += ["-isystem", p]
+        inc += ["-isystem", sysconfig.get_paths()["include"], "-isystem", "/opt/rocm/include"]
+        tlib = Path(torch.__file__).parent / "lib"
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared",
+               "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=libPrim3D",
+               "-DTORCH_API_INCLUDE_EXTENSION_H", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+               *inc, str(CSRC / "bindings.cpp"), "-o", str(out),
+               f"-L{tlib}", "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python", "-ltorch_hip", "-lc10_hip",
+               f"-L{PKG}", "-lp3dmc", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}", "-Wno-deprecated-declarations"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return out
+
+
+def build_all(force: bool = False, verbose: bool = False):
+    a = build_capi(force, verbose)
+    b = build_pybind(force, verbose)
+    return a, b
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

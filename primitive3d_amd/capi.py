@@ -1,0 +1,134 @@
+"""ctypes binding of the C ABI (include/p3d_mc.h) -- the same entry points the pybind adapter
+(csrc/bindings.cpp) calls, exposed so tests/bench can drive the library directly on raw device
+pointers.  Loading fails loudly if libp3dmc.so has not been built: there is no fallback path.
+"""
+import ctypes
+from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+from ._build import capi_path
+
+P3D_F32, P3D_F16 = 0, 1
+P3D_OK = 0
+
+# every symbol include/p3d_mc.h declares
+SYMBOLS = ("p3d_mc_abi_version", "p3d_last_error", "p3d_mc_workspace_bytes", "p3d_mc_count",
+           "p3d_mc_read_counts", "p3d_mc_emit", "p3d_mc_plane_records")
+
+
+class Slab(ctypes.Structure):
+    """p3d_mc_slab (include/p3d_mc.h)."""
+    _fields_ = [("halo_last_plane", c_int32), ("reserved", c_int32), ("vertex_id_base", c_int64),
+                ("halo_vertex_id_base", c_int64), ("x_origin", c_int64)]
+
+
+class P3DError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = capi_path()
+        if not path.exists():
+            raise ImportError(f"{path} is missing: build it with `python -m primitive3d_amd._build` "
+                              "(or __graft_entry__.build()); there is no CPU fallback")
+        L = ctypes.CDLL(str(path))
+        L.p3d_mc_abi_version.restype = c_int
+        L.p3d_last_error.restype = c_char_p
+        L.p3d_mc_workspace_bytes.argtypes = [c_int64, c_int64, c_int64, POINTER(c_size_t)]
+        L.p3d_mc_count.argtypes = [c_void_p, c_int, c_int64, c_int64, c_int64, c_float, POINTER(Slab), c_void_p, c_void_p]
+        L.p3d_mc_read_counts.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_int64), c_void_p]
+        L.p3d_mc_emit.argtypes = [c_void_p, c_int, c_int64, c_int64, c_int64, c_float, POINTER(c_float * 3),
+                                  POINTER(c_float * 3), POINTER(c_int64 * 3), POINTER(Slab), c_void_p, c_void_p,
+                                  c_int64, c_void_p, c_int64, c_void_p, c_void_p]
+        L.p3d_mc_plane_records.argtypes = [c_void_p, c_int64, c_int64, c_int64, c_int64, POINTER(c_void_p),
+                                           POINTER(c_size_t)]
+        for name in SYMBOLS:
+            getattr(L, name)  # raises AttributeError if the .so lacks a declared symbol
+            if name not in ("p3d_last_error",):
+                getattr(L, name).restype = getattr(L, name).restype or c_int
+        _LIB = L
+    return _LIB
+
+
+def _check(rc, what):
+    if rc != P3D_OK:
+        raise P3DError(f"{what} failed ({rc}): {lib().p3d_last_error().decode()}")
+
+
+def workspace_bytes(rx, ry, rz) -> int:
+    n = c_size_t(0)
+    _check(lib().p3d_mc_workspace_bytes(rx, ry, rz, byref(n)), "p3d_mc_workspace_bytes")
+    return n.value
+
+
+def _dtype_code(t):
+    import torch
+    if t.dtype == torch.float32:
+        return P3D_F32
+    if t.dtype == torch.float16:
+        return P3D_F16
+    raise TypeError(f"unsupported grid dtype {t.dtype}")
+
+
+def _stream_ptr(t):
+    import torch
+    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def count(grid, thresh, ws, slab=None):
+    """p3d_mc_count on a contiguous device tensor [rx,ry,rz]."""
+    assert grid.is_cuda and grid.is_contiguous() and grid.dim() == 3
+    rx, ry, rz = grid.shape
+    _check(lib().p3d_mc_count(c_void_p(grid.data_ptr()), _dtype_code(grid), rx, ry, rz, c_float(thresh),
+                              byref(slab) if slab is not None else None, c_void_p(ws.data_ptr()),
+                              _stream_ptr(grid)), "p3d_mc_count")
+
+
+def read_counts(ws):
+    v, f = c_int64(0), c_int64(0)
+    _check(lib().p3d_mc_read_counts(c_void_p(ws.data_ptr()), byref(v), byref(f), _stream_ptr(ws)),
+           "p3d_mc_read_counts")
+    return v.value, f.value
+
+
+def emit(grid, thresh, lower, upper, ws, vertices, faces, vertex_keys=None, slab=None, full_res=None):
+    rx, ry, rz = grid.shape
+    lo = (c_float * 3)(*[float(v) for v in lower])
+    up = (c_float * 3)(*[float(v) for v in upper])
+    fr = (c_int64 * 3)(*[int(v) for v in full_res]) if full_res is not None else None
+    capv = vertices.shape[0] if vertices is not None else 0
+    capf = faces.shape[0] if faces is not None else 0
+    _check(lib().p3d_mc_emit(c_void_p(grid.data_ptr()), _dtype_code(grid), rx, ry, rz, c_float(thresh),
+                             byref(lo), byref(up), byref(fr) if fr is not None else None,
+                             byref(slab) if slab is not None else None, c_void_p(ws.data_ptr()),
+                             c_void_p(vertices.data_ptr()) if capv else None, capv,
+                             c_void_p(faces.data_ptr()) if capf else None, capf,
+                             c_void_p(vertex_keys.data_ptr()) if vertex_keys is not None and capv else None,
+                             _stream_ptr(grid)), "p3d_mc_emit")
+
+
+def plane_records(ws, rx, ry, rz, plane):
+    ptr, n = c_void_p(0), c_size_t(0)
+    _check(lib().p3d_mc_plane_records(c_void_p(ws.data_ptr()), rx, ry, rz, plane, byref(ptr), byref(n)),
+           "p3d_mc_plane_records")
+    return ptr.value, n.value
+
+
+def extract(grid, thresh, lower=None, upper=None, with_keys=False):
+    """Whole two-phase call through the C ABI on a device tensor; returns (vertices, faces[, keys])."""
+    import torch
+    rx, ry, rz = grid.shape
+    lower = [0.0, 0.0, 0.0] if lower is None else lower
+    upper = [rx, ry, rz] if upper is None else upper
+    ws = torch.empty(workspace_bytes(rx, ry, rz), dtype=torch.uint8, device=grid.device)
+    count(grid, thresh, ws)
+    nv, nf = read_counts(ws)
+    verts = torch.empty((nv, 3), dtype=torch.float32, device=grid.device)
+    faces = torch.empty((nf, 3), dtype=torch.int32, device=grid.device)
+    keys = torch.empty((nv,), dtype=torch.int64, device=grid.device) if with_keys else None
+    emit(grid, thresh, lower, upper, ws, verts, faces, keys)
+    return (verts, faces, keys) if with_keys else (verts, faces)

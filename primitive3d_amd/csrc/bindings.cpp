@@ -1,0 +1,133 @@
+// bindings.cpp -- pybind module `libPrim3D`: the same Python-visible surface as the reference's
+// src/pybind/bindings.cpp:13-32 (marching_cubes, save_mesh_as_ply, enable_optix, test, and the two
+// ray-casting names the package imports at module load), implemented as a thin adapter over the C ABI
+// in include/p3d_mc.h.  No kernels live here: torch is used for device memory and the current stream.
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/extension.h>
+
+#include <cstdint>
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/p3d_mc.h"
+
+namespace py = pybind11;
+using torch::Tensor;
+
+namespace {
+
+void check_rc(int rc, const char* what) {
+    TORCH_CHECK(rc == P3D_OK, what, " failed (", rc, "): ", p3d_last_error());
+}
+
+// Replaces prim3d::marching_cubes, src/prim3d/Utility/marching_cubes.cu:212-305.
+// Same argument meaning and error behaviour: CUDA(HIP)+contiguous checks raise c10::Error with the
+// reference's messages (Core/common.h:63-68), ndimension()==3, float32 data (data_ptr<float>()
+// would throw in the reference, :243).  lower/upper lengths are TORCH_CHECKed (the reference only
+// asserts, :221-222, compiled out in Release).
+std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thresh, const std::vector<float> lower,
+                                   const std::vector<float> upper) {
+    TORCH_CHECK(density_grid.is_cuda(), "density_grid must be a CUDA tensor");
+    TORCH_CHECK(density_grid.is_contiguous(), "density_grid must be contiguous");
+    TORCH_CHECK(density_grid.ndimension() == 3);
+    TORCH_CHECK(lower.size() == 3 && upper.size() == 3, "lower and upper must have 3 elements");
+    TORCH_CHECK(density_grid.scalar_type() == torch::kFloat, "expected scalar type Float but found ",
+                density_grid.scalar_type());
+
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(density_grid.device());
+    void* stream = (void*)c10::hip::getCurrentHIPStream(density_grid.device().index()).stream();
+    const int64_t rx = density_grid.size(0), ry = density_grid.size(1), rz = density_grid.size(2);
+    const auto dev = density_grid.device();
+
+    size_t ws_bytes = 0;
+    check_rc(p3d_mc_workspace_bytes(rx, ry, rz, &ws_bytes), "p3d_mc_workspace_bytes");
+    Tensor ws = torch::empty({(int64_t)ws_bytes}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+
+    check_rc(p3d_mc_count(density_grid.data_ptr<float>(), P3D_F32, rx, ry, rz, thresh, nullptr, ws.data_ptr(), stream),
+             "p3d_mc_count");
+    int64_t nv = 0, nf = 0;
+    check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, stream), "p3d_mc_read_counts");
+
+    Tensor vertices = torch::empty({nv, 3}, torch::TensorOptions().dtype(torch::kFloat).device(dev));
+    Tensor faces = torch::empty({nf, 3}, torch::TensorOptions().dtype(torch::kInt).device(dev));
+    check_rc(p3d_mc_emit(density_grid.data_ptr<float>(), P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(),
+                         nullptr, nullptr, ws.data_ptr(), nv ? vertices.data_ptr<float>() : nullptr, nv,
+                         nf ? faces.data_ptr<int32_t>() : nullptr, nf, nullptr, stream),
+             "p3d_mc_emit");
+    return {vertices, faces};
+}
+
+// Replaces prim3d::save_mesh_as_ply, marching_cubes.cu:307-352: same header text and binary layout
+// (per vertex xyz f32 + rgb u8; per face int32 count 3 + 3 int32 indices), written from ONE packed
+// host buffer per section instead of a write call per vertex.
+void save_mesh_as_ply(const std::string filename, Tensor vertices, Tensor faces, Tensor colors) {
+    TORCH_CHECK(vertices.is_contiguous(), "vertices must be contiguous");
+    TORCH_CHECK(faces.is_contiguous(), "faces must be contiguous");
+    TORCH_CHECK(colors.is_contiguous(), "colors must be contiguous");
+    TORCH_CHECK(colors.scalar_type() == torch::kUInt8, "colors must be uint8");
+    vertices = vertices.to(torch::kCPU).to(torch::kFloat).contiguous();
+    faces = faces.to(torch::kCPU).to(torch::kInt).contiguous();
+    colors = colors.to(torch::kCPU).contiguous();
+    const int64_t nv = vertices.size(0), nf = faces.size(0);
+
+    std::ofstream ply(filename, std::ios::out | std::ios::binary);
+    ply << "ply\n";
+    ply << "format binary_little_endian 1.0\n";
+    ply << "element vertex " << nv << std::endl;
+    ply << "property float x\n";
+    ply << "property float y\n";
+    ply << "property float z\n";
+    ply << "property uchar red\n";
+    ply << "property uchar green\n";
+    ply << "property uchar blue\n";
+    ply << "element face " << nf << std::endl;
+    ply << "property list int int vertex_index\n";
+    ply << "end_header\n";
+
+    std::vector<char> vbuf((size_t)nv * 15);
+    const float* vp = vertices.data_ptr<float>();
+    const uint8_t* cp = colors.data_ptr<uint8_t>();
+    for (int64_t i = 0; i < nv; ++i) {
+        std::memcpy(&vbuf[(size_t)i * 15], vp + i * 3, 12);
+        std::memcpy(&vbuf[(size_t)i * 15 + 12], cp + i * 3, 3);
+    }
+    ply.write(vbuf.data(), (std::streamsize)vbuf.size());
+
+    std::vector<int32_t> fbuf((size_t)nf * 4);
+    const int32_t* fp = faces.data_ptr<int32_t>();
+    for (int64_t i = 0; i < nf; ++i) {
+        fbuf[(size_t)i * 4] = 3;
+        fbuf[(size_t)i * 4 + 1] = fp[i * 3];
+        fbuf[(size_t)i * 4 + 2] = fp[i * 3 + 1];
+        fbuf[(size_t)i * 4 + 3] = fp[i * 3 + 2];
+    }
+    ply.write((const char*)fbuf.data(), (std::streamsize)(fbuf.size() * sizeof(int32_t)));
+    ply.close();
+}
+
+void test() { std::cout << "hello world!" << std::endl; }  // Core/utils.cpp:10-12
+
+// Ray casting (OptiX / BVH) is outside this build's scope: the names exist so
+// that `prim3d.utility.ray_cast`'s import-time annotation resolves; using them raises.
+struct RayCaster {
+    void invoke(py::args, py::kwargs) { throw std::runtime_error("RayCaster is not part of the MI355X marching-cubes build"); }
+};
+py::object create_raycaster(py::args, py::kwargs) {
+    throw std::runtime_error("create_raycaster is not part of the MI355X marching-cubes build");
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.doc() = "Primitive3D marching cubes, MI355X-native (HIP/CDNA4) build.";
+    m.attr("enable_optix") = false;
+    m.def("test", &test);
+    py::class_<RayCaster>(m, "RayCaster").def("invoke", &RayCaster::invoke);
+    m.def("create_raycaster", &create_raycaster);
+    m.def("marching_cubes", &marching_cubes);
+    m.def("save_mesh_as_ply", &save_mesh_as_ply);
+}

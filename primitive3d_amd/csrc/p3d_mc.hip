@@ -1,0 +1,660 @@
+// p3d_mc.hip -- MI355X (gfx950 / CDNA4) marching-cubes hot path + its C ABI (include/p3d_mc.h).
+//
+// What this replaces (paths into lzhnb/Primitive3D):
+//   count_vertices_faces_kernel / gen_vertices_kernel / gen_faces_kernel and their host driver,
+//   src/prim3d/Utility/marching_cubes.cu:4-305.
+//
+// Design: the scalar field is read ONCE, coalesced along the contiguous z axis, with
+// one lane per voxel of a 64-voxel "unit"; the wave64 compare result (v_cmp -> SGPR pair) IS the
+// unit's sign word, so classification costs one VALU instruction per 64 voxels.  Everything after
+// that (edge crossings, cell masks, counts, prefix sums, vertex ids) is bit arithmetic on those
+// words (1 bit/voxel, L2/Infinity-Cache resident) instead of the reference's 12 B/voxel
+// vertex_grids and per-cell global atomics.
+//
+//   unit u = (x*ry + y)*ncz + c   <->  voxels (x, y, 64c .. 64c+63),  ncz = ceil(rz/64)
+//   bits[u]  : u64, bit k = field(x,y,64c+k) > thresh           (strict >, marching_cubes.cu:25)
+//   rec[u]   : {base, offY | offZ<<16}: vertex ids of the unit's edges are
+//                 axis0 (x edges): base        + rank among Cx bits below
+//                 axis1 (y edges): base + offY + rank among Cy bits below
+//                 axis2 (z edges): base + offZ + rank among Cz bits below
+//              with Cx = bits[u]^bits[u+P], Cy = bits[u]^bits[u+ncz], Cz = bits[u]^(bits[u]>>1|next<<63)
+//
+// No CUDA-compat shims, no dual paths: gfx950 only (wave64 hard-coded).
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "../../include/p3d_mc.h"
+#include "tri_table_packed.inc"
+
+namespace {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+__device__ const u64 g_tri_packed[256] = {P3D_TRI_TABLE_PACKED};
+__device__ const unsigned char g_tri_count[256] = {P3D_TRI_COUNT};
+
+struct Dims {
+    int64_t rx, ry, rz;
+    int64_t P;  // units per x plane = ry * ncz
+    int64_t U;  // total units
+    int ncz;    // 64-voxel chunks per z row
+    int ztail;  // rz % 64
+};
+
+struct Ws {  // byte offsets into the workspace
+    size_t hdr, bits, rec, cnt, bsum_v, bbase_v, bsum_f, bbase_f, total;
+    int64_t nb_v, nb_f, tpp;  // unit blocks, face blocks, face tiles per plane
+};
+
+constexpr int kBlock = 256;
+constexpr int kHdrBytes = 256;
+// header slots (u64)
+enum { H_V = 0, H_T = 1 };
+
+__host__ __device__ inline Dims make_dims(int64_t rx, int64_t ry, int64_t rz) {
+    Dims d;
+    d.rx = rx;
+    d.ry = ry;
+    d.rz = rz;
+    d.ncz = (int)((rz + 63) / 64);
+    d.ztail = (int)(rz % 64);
+    d.P = ry * d.ncz;
+    d.U = rx * d.P;
+    return d;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+Ws make_ws(const Dims& d) {
+    Ws w;
+    w.nb_v = (d.U + kBlock - 1) / kBlock;
+    w.tpp = (d.P + kBlock - 1) / kBlock;
+    w.nb_f = (d.rx > 1 ? d.rx - 1 : 0) * w.tpp;
+    size_t o = 0;
+    w.hdr = o;
+    o += kHdrBytes;
+    w.bits = o;
+    o = align_up(o + (size_t)(d.U + 2) * 8, 256);
+    w.rec = o;
+    o = align_up(o + (size_t)(d.U + 2) * 8, 256);
+    w.cnt = o;
+    o = align_up(o + (size_t)d.U * 4, 256);
+    w.bsum_v = o;
+    o = align_up(o + (size_t)w.nb_v * 4, 256);
+    w.bbase_v = o;
+    o = align_up(o + (size_t)w.nb_v * 4, 256);
+    w.bsum_f = o;
+    o = align_up(o + (size_t)(w.nb_f + 1) * 4, 256);
+    w.bbase_f = o;
+    o = align_up(o + (size_t)(w.nb_f + 1) * 4, 256);
+    w.total = o;
+    return w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ inline u64 zmask(const Dims& d, int c) {  // voxels of chunk c that exist (z < rz)
+    return (c == d.ncz - 1 && d.ztail) ? ((1ull << d.ztail) - 1ull) : ~0ull;
+}
+__device__ inline u64 zedge(const Dims& d, int c) {  // voxels of chunk c whose z+1 neighbour exists
+    if (c != d.ncz - 1) return ~0ull;
+    const int last = d.ztail ? d.ztail : 64;  // voxels in the last chunk
+    return last >= 2 ? ((1ull << (last - 1)) - 1ull) : 0ull;  // last-1 <= 63
+}
+__device__ inline int popc64(u64 v) { return __popcll(v); }
+__device__ inline u64 below(int k) { return (1ull << k) - 1ull; }  // k in [0,63]
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
+template <int I, int N, typename F>
+__device__ inline void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// w[lane J] = v (v wave-uniform).  The lane select must be an inline constant: on gfx9 a VOP3 may read
+// only one SGPR, and the value already is one.
+template <int J>
+__device__ inline void write_lane(int& w, int v) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(w) : "s"(v), "n"(J));
+}
+
+__device__ inline float load_f32(const float* p) { return *p; }
+__device__ inline float load_f32(const __half* p) { return __half2float(*p); }
+
+__device__ inline u32 block_reduce_sum(u32 v, u32* s_tmp /* >= 4 */) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) s_tmp[wave] = v;
+    __syncthreads();
+    return s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+}
+
+// exclusive scan over the 256 threads of a block; *total receives the block sum
+__device__ inline u32 block_excl_scan(u32 v, u32* s_tmp /* >= 4 */, u32* total) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u32 inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        u32 t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) s_tmp[wave] = inc;
+    __syncthreads();
+    u32 wbase = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        if (w < wave) wbase += s_tmp[w];
+    *total = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+    return wbase + inc - v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: classify.  HBM-bound stream over the field: one lane per voxel, the wave-wide compare result
+// is the unit's sign word.  64 words are collected across lanes (v_writelane) and stored coalesced.
+// Replaces the `density > thresh` tests of marching_cubes.cu:25,31,38,45,50-57,103,116,129,169-176.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_classify(const T* __restrict__ grid, float thresh, Dims d,
+                                                     u64* __restrict__ bits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+    const int64_t nrows = d.rx * d.ry;
+    const int64_t nvox = nrows * d.rz;
+    for (int64_t u0 = wave * 64; u0 < d.U; u0 += nwaves * 64) {
+        int64_t row = u0 / d.ncz;
+        int c = (int)(u0 - row * d.ncz);
+        int wlo = 0, whi = 0;
+        static_for<0, 64>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int z = c * 64 + lane;
+            int64_t idx = row * d.rz + z;
+            idx = idx < nvox ? idx : nvox - 1;  // clamp: the load is unconditional, the predicate is not
+            const float v = load_f32(grid + idx);
+            const bool inside = (row < nrows) && (z < d.rz) && (v > thresh);
+            const u64 m = __ballot(inside);
+            write_lane<j>(wlo, (int)(u32)m);
+            write_lane<j>(whi, (int)(u32)(m >> 32));
+            if (++c == d.ncz) {
+                c = 0;
+                ++row;
+            }
+        });
+        if (u0 + lane < d.U) bits[u0 + lane] = ((u64)(u32)whi << 32) | (u32)wlo;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: per-unit edge-crossing counts (lane = unit) + block sums.  All inputs are sign words.
+// Replaces the three atomicAdd(counters, 1) of marching_cubes.cu:29-45.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_unit_counts(const u64* __restrict__ bits, Dims d, int halo_last,
+                                                        u32* __restrict__ cnt, u32* __restrict__ bsum) {
+    __shared__ u32 s_tmp[4];
+    const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    u32 n = 0;
+    if (u < d.U) {
+        const int64_t x = u / d.P;
+        const int64_t p = u - x * d.P;
+        const int64_t y = p / d.ncz;
+        const int c = (int)(p - y * d.ncz);
+        const u64 W = bits[u];
+        const u64 zm = zmask(d, c);
+        u32 nX = 0, nY = 0, nZ = 0;
+        if (x + 1 < d.rx) nX = popc64((W ^ bits[u + d.P]) & zm);
+        if (!(halo_last && x == d.rx - 1)) {
+            if (y + 1 < d.ry) nY = popc64((W ^ bits[u + d.ncz]) & zm);
+            const u64 nb = (c + 1 < d.ncz) ? (bits[u + 1] & 1ull) : 0ull;
+            nZ = popc64((W ^ ((W >> 1) | (nb << 63))) & zedge(d, c));
+        }
+        cnt[u] = nX | (nY << 8) | (nZ << 16);
+        n = nX + nY + nZ;
+    }
+    const u32 tot = block_reduce_sum(n, s_tmp);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+// exclusive scan of block sums by ONE block (nb is small: units/256 or face tiles)
+__global__ void __launch_bounds__(1024) k_scan_blocks(const u32* __restrict__ bsum, u32* __restrict__ bbase,
+                                                      int64_t nb, u64* __restrict__ total_out) {
+    __shared__ u64 s_w[16];
+    __shared__ u64 s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t i0 = 0; i0 < nb; i0 += 1024) {
+        const int64_t i = i0 + tid;
+        const u64 v = (i < nb) ? bsum[i] : 0;
+        u64 inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            u64 t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        u64 wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += s_w[w];
+        const u64 carry = s_carry;
+        if (i < nb) {
+            const u64 e = carry + wbase + inc - v;
+            bbase[i] = (u32)(e > 0xffffffffull ? 0xffffffffull : e);
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + wbase + inc;
+        __syncthreads();
+    }
+    if (tid == 0) *total_out = s_carry;
+}
+
+// per-unit vertex-id records from counts + scanned block bases
+__global__ void __launch_bounds__(kBlock) k_unit_records(const u32* __restrict__ cnt, const u32* __restrict__ bbase,
+                                                         Dims d, int halo_last, uint2* __restrict__ rec) {
+    __shared__ u32 s_tmp[4];
+    const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const u32 cw = (u < d.U) ? cnt[u] : 0;
+    const u32 nX = cw & 0xff, nY = (cw >> 8) & 0xff, nZ = (cw >> 16) & 0xff;
+    u32 tot;
+    const u32 ex = block_excl_scan(nX + nY + nZ, s_tmp, &tot);
+    if (u < d.U) {
+        const bool is_halo = halo_last && (u >= (d.rx - 1) * d.P);
+        if (!is_halo) rec[u] = make_uint2(bbase[blockIdx.x] + ex, nX | ((nX + nY) << 16));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3 (exact mode): vertex emission by gather -- one wave per unit with crossings, lane = voxel.
+// Arithmetic follows gen_vertices_kernel (marching_cubes.cu:100-135) and the epilogue (:290-298)
+// operation for operation: IEEE divide, float(coord)+dt, then a separately rounded multiply and add.
+// ---------------------------------------------------------------------------------------------
+struct Xform {
+    float sx, sy, sz, ox, oy, oz;
+};
+
+__device__ inline void put_vertex(float* __restrict__ verts, int64_t* __restrict__ keys, int64_t cap, u32 vid,
+                                  float px, float py, float pz, const Xform& t, int64_t key) {
+    if ((int64_t)vid < cap) {
+        float* o = verts + (int64_t)vid * 3;
+        o[0] = __fadd_rn(__fmul_rn(px, t.sx), t.ox);
+        o[1] = __fadd_rn(__fmul_rn(py, t.sy), t.oy);
+        o[2] = __fadd_rn(__fmul_rn(pz, t.sz), t.oz);
+        if (keys) keys[vid] = key;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_emit_vertices(const T* __restrict__ grid, float thresh, Dims d,
+                                                          const u64* __restrict__ bits, const u32* __restrict__ cnt,
+                                                          const uint2* __restrict__ rec, Xform t, int64_t x_origin,
+                                                          float* __restrict__ verts, int64_t cap,
+                                                          int64_t* __restrict__ keys) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+    const u64 lt = below(lane);
+    for (int64_t u = wave; u < d.U; u += nwaves) {
+        const u32 cw = cnt[u];
+        if (cw == 0) continue;  // wave-uniform
+        const int64_t x = u / d.P;
+        const int64_t p = u - x * d.P;
+        const int64_t y = p / d.ncz;
+        const int c = (int)(p - y * d.ncz);
+        const u64 W = bits[u];
+        const u64 zm = zmask(d, c);
+        const u64 Cx = (cw & 0xff) ? ((W ^ bits[u + d.P]) & zm) : 0ull;
+        const u64 Cy = ((cw >> 8) & 0xff) ? ((W ^ bits[u + d.ncz]) & zm) : 0ull;
+        u64 Cz = 0;
+        if ((cw >> 16) & 0xff) {
+            const u64 nb = (c + 1 < d.ncz) ? (bits[u + 1] & 1ull) : 0ull;
+            Cz = (W ^ ((W >> 1) | (nb << 63))) & zedge(d, c);
+        }
+        const uint2 r = rec[u];
+        const int z = c * 64 + lane;
+        const int64_t lin = (x * d.ry + y) * d.rz + z;
+        const bool zin = z < d.rz;
+        const float d0 = zin ? load_f32(grid + lin) : 0.f;
+        const float fx = (float)(x + x_origin), fy = (float)y, fz = (float)z;
+        if ((Cx >> lane) & 1ull) {
+            const float d1 = load_f32(grid + lin + d.ry * d.rz);
+            const float dt = (thresh - d0) / (d1 - d0);
+            put_vertex(verts, keys, cap, r.x + popc64(Cx & lt), fx + dt, fy, fz, t, lin * 3 + 0);
+        }
+        if ((Cy >> lane) & 1ull) {
+            const float d1 = load_f32(grid + lin + d.rz);
+            const float dt = (thresh - d0) / (d1 - d0);
+            put_vertex(verts, keys, cap, r.x + (r.y & 0xffff) + popc64(Cy & lt), fx, fy + dt, fz, t, lin * 3 + 1);
+        }
+        if ((Cz >> lane) & 1ull) {
+            const float d1 = load_f32(grid + lin + 1);
+            const float dt = (thresh - d0) / (d1 - d0);
+            put_vertex(verts, keys, cap, r.x + (r.y >> 16) + popc64(Cz & lt), fx, fy, fz + dt, t, lin * 3 + 2);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: faces from sign words + vertex-id records.  One block = 256 units of one x plane.
+//   phase A (lane = unit): load the 2x2 column words and their z+1 shifts, active-cell word
+//   phase B: expand active cells into a dense LDS list
+//   phase C (lane = active cell): 8-bit corner mask, triangle count; block sum
+//   EMIT: second sweep writes indices at bbase[block] + running offset
+// Corner bit weights and edge numbering follow marching_cubes.cu:49-57 and :178-192.
+// ---------------------------------------------------------------------------------------------
+struct FaceArgs {
+    int halo_last;
+    int64_t vid_base, halo_vid_base;
+    int64_t tpp;  // tiles per plane
+};
+
+// owner column (0:(x,y) 1:(x+1,y) 2:(x+1,y+1) 3:(x,y+1)), dz, axis for the 12 cell edges
+__device__ inline void edge_owner(int e, int& col, int& dz, int& axis) {
+    // packed as col | dz<<2 | axis<<3, 5 bits per edge
+    const u64 tab = (u64)(0 | 0 << 2 | 0 << 3) << 0 |    // e0  (x,y,z)     axis0
+                    (u64)(1 | 0 << 2 | 1 << 3) << 5 |    // e1  (x+1,y,z)   axis1
+                    (u64)(3 | 0 << 2 | 0 << 3) << 10 |   // e2  (x,y+1,z)   axis0
+                    (u64)(0 | 0 << 2 | 1 << 3) << 15 |   // e3  (x,y,z)     axis1
+                    (u64)(0 | 1 << 2 | 0 << 3) << 20 |   // e4  (x,y,z+1)   axis0
+                    (u64)(1 | 1 << 2 | 1 << 3) << 25 |   // e5  (x+1,y,z+1) axis1
+                    (u64)(3 | 1 << 2 | 0 << 3) << 30 |   // e6  (x,y+1,z+1) axis0
+                    (u64)(0 | 1 << 2 | 1 << 3) << 35 |   // e7  (x,y,z+1)   axis1
+                    (u64)(0 | 0 << 2 | 2 << 3) << 40 |   // e8  (x,y,z)     axis2
+                    (u64)(1 | 0 << 2 | 2 << 3) << 45 |   // e9  (x+1,y,z)   axis2
+                    (u64)(2 | 0 << 2 | 2 << 3) << 50 |   // e10 (x+1,y+1,z) axis2
+                    (u64)(3 | 0 << 2 | 2 << 3) << 55;    // e11 (x,y+1,z)   axis2
+    const int v = (int)((tab >> (5 * e)) & 31);
+    col = v & 3;
+    dz = (v >> 2) & 1;
+    axis = v >> 3;
+}
+
+template <bool EMIT>
+__global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, const uint2* __restrict__ rec, Dims d,
+                                                  FaceArgs a, const u32* __restrict__ bbase, u32* __restrict__ bsum,
+                                                  int32_t* __restrict__ faces, int64_t cap_faces) {
+    __shared__ u64 s_tab[256];
+    __shared__ unsigned char s_ntri[256];
+    __shared__ u64 s_w[kBlock][8];  // W00,W10,W11,W01 then their z+1 shifts: bit k of word j = corner j of cell k
+    __shared__ unsigned short s_cells[kBlock * 64];
+    __shared__ u32 s_tmp[4];
+
+    const int tid = threadIdx.x;
+    s_tab[tid] = g_tri_packed[tid];
+    s_ntri[tid] = g_tri_count[tid];
+
+    const int64_t b = blockIdx.x;
+    const int64_t x = b / a.tpp;
+    const int64_t tile = b - x * a.tpp;
+    const int64_t p = tile * kBlock + tid;
+    const int64_t y = p / d.ncz;
+    const int c = (int)(p - y * d.ncz);
+    const int64_t u = x * d.P + p;
+    const bool valid = (p < d.P) && (y + 1 < d.ry);  // x+1 < rx by grid construction
+
+    u64 act = 0;
+    if (valid) {
+        const int64_t uc[4] = {u, u + d.P, u + d.P + d.ncz, u + d.ncz};
+        u64 orr = 0, andd = ~0ull;
+        const bool more = c + 1 < d.ncz;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u64 W = bits[uc[k]];
+            const u64 nb = more ? (bits[uc[k] + 1] & 1ull) : 0ull;
+            const u64 S = (W >> 1) | (nb << 63);
+            s_w[tid][k] = W;
+            s_w[tid][4 + k] = S;
+            orr |= W | S;
+            andd &= W & S;
+        }
+        act = orr & ~andd & zedge(d, c);
+    }
+    u32 na_total;
+    u32 off = block_excl_scan((u32)popc64(act), s_tmp, &na_total);
+    while (act) {
+        const int z = __ffsll((long long)act) - 1;
+        act &= act - 1;
+        s_cells[off++] = (unsigned short)((tid << 6) | z);
+    }
+    __syncthreads();
+
+    // phase C: count triangles
+    u32 my_tris = 0;
+    for (u32 i = tid; i < na_total; i += kBlock) {
+        const int cell = s_cells[i];
+        const int t = cell >> 6, z = cell & 63;
+        int mask = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mask |= (int)((s_w[t][k] >> z) & 1ull) << k;
+        my_tris += s_ntri[mask];
+    }
+    const u32 tile_tris = block_reduce_sum(my_tris, s_tmp);
+    if (!EMIT) {
+        if (tid == 0) bsum[b] = tile_tris;
+        return;
+    }
+    if (tile_tris == 0) return;
+
+    // EMIT sweep: batches of 256 cells, running offset kept in every thread
+    const bool xhalo = a.halo_last && (x + 1 == d.rx - 1);  // columns 1,2 live in the imported plane
+    u32 run = bbase[b];
+    for (u32 i0 = 0; i0 < na_total; i0 += kBlock) {
+        const u32 i = i0 + tid;
+        int mask = 0, t = 0, z = 0;
+        if (i < na_total) {
+            const int cell = s_cells[i];
+            t = cell >> 6;
+            z = cell & 63;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mask |= (int)((s_w[t][k] >> z) & 1ull) << k;
+        }
+        const u32 nt = s_ntri[mask];
+        u32 batch_total;
+        const u32 o = block_excl_scan(nt, s_tmp, &batch_total);
+        if (nt) {
+            const int64_t pu = tile * kBlock + t;            // unit of this cell within the plane
+            const int64_t ucol[4] = {x * d.P + pu, x * d.P + pu + d.P, x * d.P + pu + d.P + d.ncz,
+                                     x * d.P + pu + d.ncz};
+            const u64 row = s_tab[mask];
+            const int64_t fbase = ((int64_t)run + o) * 3;
+            for (u32 k = 0; k < nt * 3; ++k) {
+                const int e = (int)((row >> (4 * k)) & 0xF);
+                int col, dz, axis;
+                edge_owner(e, col, dz, axis);
+                int zz = z + dz;
+                int64_t ou = ucol[col];
+                u32 rank;
+                if (zz == 64) {  // first voxel of the next chunk: no bits below it
+                    ou += 1;
+                    rank = 0;
+                } else {
+                    // crossing word of (col, axis) within this chunk
+                    u64 C;
+                    const u64 W = s_w[t][col];
+                    if (axis == 2) C = W ^ s_w[t][4 + col];
+                    else if (axis == 0) C = W ^ s_w[t][col == 0 ? 1 : 2];  // col 0 -> (x+1,y) ; col 3 -> (x+1,y+1)
+                    else C = W ^ s_w[t][col == 0 ? 3 : 2];                 // col 0 -> (x,y+1) ; col 1 -> (x+1,y+1)
+                    rank = (u32)popc64(C & below(zz));
+                }
+                const uint2 r = rec[ou];
+                const u32 offa = axis == 0 ? 0u : (axis == 1 ? (r.y & 0xffffu) : (r.y >> 16));
+                const bool in_halo = xhalo && (col == 1 || col == 2);
+                const int64_t vid = (int64_t)r.x + offa + rank + (in_halo ? a.halo_vid_base : a.vid_base);
+                if (fbase + k < cap_faces * 3) faces[fbase + k] = (int32_t)vid;
+            }
+        }
+        run += batch_total;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* detail = "") {
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) return fail(P3D_EHIP, #expr ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+int check_dims(int64_t rx, int64_t ry, int64_t rz) {
+    if (rx < 1 || ry < 1 || rz < 1) return fail(P3D_EINVAL, "grid dims must be >= 1%s");
+    const Dims d = make_dims(rx, ry, rz);
+    // int32 vertex ids / 32-bit block bases: refuse grids whose worst case cannot be indexed safely
+    if (d.U >= (1ll << 31) || rx * ry >= (1ll << 40)) return fail(P3D_ERANGE, "grid too large%s");
+    return P3D_OK;
+}
+
+int grid_for(int64_t work_items, int per_block, int64_t cap) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+template <typename T>
+int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3d_mc_slab* slab, char* ws,
+               hipStream_t st) {
+    const int halo = slab ? slab->halo_last_plane : 0;
+    u64* hdr = (u64*)(ws + w.hdr);
+    u64* bits = (u64*)(ws + w.bits);
+    uint2* rec = (uint2*)(ws + w.rec);
+    u32* cnt = (u32*)(ws + w.cnt);
+    u32 *bsv = (u32*)(ws + w.bsum_v), *bbv = (u32*)(ws + w.bbase_v);
+    u32 *bsf = (u32*)(ws + w.bsum_f), *bbf = (u32*)(ws + w.bbase_f);
+
+    // classify: 64 units (16 KiB of fp32) per wave iteration; cap the grid and stride the rest
+    const int64_t wave_iters = (d.U + 63) / 64;
+    hipLaunchKernelGGL(k_classify<T>, dim3(grid_for(wave_iters, kBlock / 64, 256 * 16)), dim3(kBlock), 0, st, grid,
+                       thresh, d, bits);
+    hipLaunchKernelGGL(k_unit_counts, dim3((u32)w.nb_v), dim3(kBlock), 0, st, bits, d, halo, cnt, bsv);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, bsv, bbv, w.nb_v, hdr + H_V);
+    hipLaunchKernelGGL(k_unit_records, dim3((u32)w.nb_v), dim3(kBlock), 0, st, cnt, bbv, d, halo, rec);
+    if (w.nb_f > 0) {
+        FaceArgs a{halo, 0, 0, w.tpp};
+        hipLaunchKernelGGL(k_faces<false>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, bbf, bsf,
+                           (int32_t*)nullptr, (int64_t)0);
+    }
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, bsf, bbf, w.nb_f, hdr + H_T);
+    HIP_TRY(hipGetLastError());
+    return P3D_OK;
+}
+
+template <typename T>
+int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xform& t, const p3d_mc_slab* slab,
+              char* ws, float* verts, int64_t capv, int32_t* faces, int64_t capf, int64_t* keys, hipStream_t st) {
+    const int halo = slab ? slab->halo_last_plane : 0;
+    u64* bits = (u64*)(ws + w.bits);
+    uint2* rec = (uint2*)(ws + w.rec);
+    u32* cnt = (u32*)(ws + w.cnt);
+    u32 *bsf = (u32*)(ws + w.bsum_f), *bbf = (u32*)(ws + w.bbase_f);
+    if (capv > 0)
+        hipLaunchKernelGGL(k_emit_vertices<T>, dim3(grid_for(d.U, kBlock / 64, 256 * 32)), dim3(kBlock), 0, st, grid,
+                           thresh, d, bits, cnt, rec, t, slab ? slab->x_origin : (int64_t)0, verts, capv, keys);
+    if (w.nb_f > 0 && capf > 0) {
+        FaceArgs a{halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0, w.tpp};
+        hipLaunchKernelGGL(k_faces<true>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, bbf, bsf, faces,
+                           capf);
+    }
+    HIP_TRY(hipGetLastError());
+    return P3D_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int p3d_mc_abi_version(void) { return P3D_MC_ABI_VERSION; }
+const char* p3d_last_error(void) { return g_err; }
+
+int p3d_mc_workspace_bytes(int64_t rx, int64_t ry, int64_t rz, size_t* bytes) {
+    if (!bytes) return fail(P3D_EINVAL, "bytes is null%s");
+    if (int rc = check_dims(rx, ry, rz)) return rc;
+    *bytes = make_ws(make_dims(rx, ry, rz)).total;
+    return P3D_OK;
+}
+
+int p3d_mc_count(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz, float thresh,
+                 const p3d_mc_slab* slab, void* ws, void* stream) {
+    if (!grid || !ws) return fail(P3D_EINVAL, "null pointer%s");
+    if (int rc = check_dims(rx, ry, rz)) return rc;
+    const Dims d = make_dims(rx, ry, rz);
+    const Ws w = make_ws(d);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == P3D_F32) return count_impl((const float*)grid, d, w, thresh, slab, (char*)ws, st);
+    if (dtype == P3D_F16) return count_impl((const __half*)grid, d, w, thresh, slab, (char*)ws, st);
+    return fail(P3D_EINVAL, "unknown dtype%s");
+}
+
+int p3d_mc_read_counts(const void* ws, int64_t* num_vertices, int64_t* num_faces, void* stream) {
+    if (!ws || !num_vertices || !num_faces) return fail(P3D_EINVAL, "null pointer%s");
+    u64 h[2] = {0, 0};
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(h, ws, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *num_vertices = (int64_t)h[H_V];
+    *num_faces = (int64_t)h[H_T];
+    if (h[H_V] > 0x7fffffffull || h[H_T] * 3 > 0x7fffffffull * 3)
+        return fail(P3D_ERANGE, "vertex/face count exceeds int32 indexing%s");
+    return P3D_OK;
+}
+
+int p3d_mc_emit(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz, float thresh, const float lower[3],
+                const float upper[3], const int64_t full_res[3], const p3d_mc_slab* slab, void* ws, float* vertices,
+                int64_t cap_vertices, int32_t* faces, int64_t cap_faces, int64_t* vertex_keys, void* stream) {
+    if (!grid || !ws || !lower || !upper) return fail(P3D_EINVAL, "null pointer%s");
+    if ((cap_vertices > 0 && !vertices) || (cap_faces > 0 && !faces)) return fail(P3D_EINVAL, "null output%s");
+    if (int rc = check_dims(rx, ry, rz)) return rc;
+    const Dims d = make_dims(rx, ry, rz);
+    const Ws w = make_ws(d);
+    const int64_t fr[3] = {full_res ? full_res[0] : rx, full_res ? full_res[1] : ry, full_res ? full_res[2] : rz};
+    // marching_cubes.cu:293-297 verbatim, including the upper[2]-lower[1] term of :295 (fp32 arithmetic)
+    Xform t;
+    t.sx = (upper[0] - lower[0]) / static_cast<float>(fr[0]);
+    t.sy = (upper[2] - lower[1]) / static_cast<float>(fr[1]);
+    t.sz = (upper[2] - lower[2]) / static_cast<float>(fr[2]);
+    t.ox = lower[0];
+    t.oy = lower[1];
+    t.oz = lower[2];
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == P3D_F32)
+        return emit_impl((const float*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices, faces,
+                         cap_faces, vertex_keys, st);
+    if (dtype == P3D_F16)
+        return emit_impl((const __half*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices, faces,
+                         cap_faces, vertex_keys, st);
+    return fail(P3D_EINVAL, "unknown dtype%s");
+}
+
+int p3d_mc_plane_records(void* ws, int64_t rx, int64_t ry, int64_t rz, int64_t plane, void** records,
+                         size_t* bytes_per_plane) {
+    if (!ws || !records || !bytes_per_plane) return fail(P3D_EINVAL, "null pointer%s");
+    if (int rc = check_dims(rx, ry, rz)) return rc;
+    if (plane < 0 || plane >= rx) return fail(P3D_EINVAL, "plane out of range%s");
+    const Dims d = make_dims(rx, ry, rz);
+    const Ws w = make_ws(d);
+    *records = (char*)ws + w.rec + (size_t)plane * d.P * sizeof(uint2);
+    *bytes_per_plane = (size_t)d.P * sizeof(uint2);
+    return P3D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,31 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Build (if stale) and import the native artefacts; every test that touches them depends on this."""
+    from primitive3d_amd import _build
+    _build.build_all()
+    import primitive3d_amd
+    return primitive3d_amd
+
+
+@pytest.fixture(scope="session")
+def gpu(built):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("test marked gpu but no GPU is visible (torch.cuda.is_available() is False)")
+    return torch.device("cuda:0")
