@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the marching-cubes hot path (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" is one whole call of the drop-in boundary (`libPrim3D.marching_cubes`: classify+count ->
+host read of V,F -> allocation -> vertex + face emission incl. the scale/offset epilogue) on a
+device-resident fp32 grid.  Workload per rank is fixed at 2^27 voxels (weak scaling):
+  N=1  512^3           single-octave Perlin SDF, period 64, iso 0  (BASELINE.json configs[2])
+  N=2  1024x512x512    axis-0 slabs, one halo plane per boundary over RCCL
+  N=4  1024x1024x512
+  N=8  1024^3          (BASELINE.json configs[3])
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant
+kernel (hipEvent-timed inside the library, on the launch stream) and `cpu_baseline` (the CPU oracle
+restatement of the reference kernels, 1 core, timed on the same grid; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+
+SHAPES = {1: (512, 512, 512), 2: (1024, 512, 512), 4: (1024, 1024, 512), 8: (1024, 1024, 1024)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=0, help="override: cubic grid of this size (N=1 only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stages", action="store_true", help="also print per-stage hipEvent times to stderr")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import primitive3d_amd as p3d
+    from primitive3d_amd import capi
+    from primitive3d_amd.fields import perlin_grid
+
+    if world == 1:
+        shape = (args.size,) * 3 if args.size else SHAPES[1]
+    else:
+        if world not in SHAPES:
+            sys.exit(f"unsupported world size {world}")
+        shape = SHAPES[world]
+    rx, ry, rz = shape
+    thresh = 0.0
+    lower, upper = [0.0, 0.0, 0.0], [float(rx), float(ry), float(rz)]
+
+    if world == 1:
+        grid = perlin_grid(shape, period=64, seed=0, device=dev)
+
+        def step():
+            return p3d.libPrim3D.marching_cubes(grid, thresh, lower, upper)
+    else:
+        from primitive3d_amd.slab import SlabExtractor
+        ex = SlabExtractor(shape, rank, world, dev)
+        ex.fill_local(lambda x0, x1: perlin_grid(shape, period=64, seed=0, device=dev, x0=x0, x1=x1))
+
+        def step():
+            return ex.extract(thresh, lower, upper)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+
+    capi.profile_enable(2 if args.stages else 1)
+    dom_ms = []
+    stage_acc = {}
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+        st = capi.profile_read()  # events of kernels that already finished (the host read V,F after them)
+        dom_ms.append(st.get("k_classify", float("nan")))
+        for k, v in st.items():
+            stage_acc[k] = stage_acc.get(k, 0.0) + v
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    capi.profile_enable(0)
+
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    nvox_total = rx * ry * rz
+    ms_per_step = elapsed / args.steps * 1e3
+    value = nvox_total * args.steps / elapsed / 1e6
+
+    nv, nf = int(out[0].shape[0]), int(out[1].shape[0])
+    if world > 1:
+        cnt = torch.tensor([nv, nf], dtype=torch.int64, device=dev)
+        dist.all_reduce(cnt)
+        nv, nf = int(cnt[0]), int(cnt[1])
+
+    if rank == 0:
+        # roofline of the dominant kernel: algorithmic bytes = the field read once
+        local_vox = nvox_total // world
+        alg_bytes = local_vox * 4
+        avg_ms = sum(dom_ms) / len(dom_ms)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = ROOT / "profiles" / "traffic.json"
+        if tfile.exists():
+            try:
+                traffic = json.loads(tfile.read_text()).get("k_classify_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "k_classify", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "avg_kernel_ms": round(avg_ms, 4), "alg_bytes_per_launch": alg_bytes,
+                    "whole_call_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if args.stages:
+            print("stage ms/step:", {k: round(v / args.steps, 4) for k, v in stage_acc.items()}, file=sys.stderr)
+
+        line = {
+            "metric": "Mvoxels/s on 512^3 fp32 SDF (whole marching_cubes call, device-resident grid)",
+            "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{rx}x{ry}x{rz} fp32 single-octave Perlin SDF (period 64, seed 0), iso 0",
+                       "voxels_per_gpu": local_vox, "vertices": nv, "faces": nf,
+                       "partition": "none" if world == 1 else f"axis-0 slabs x{world}, 1-plane RCCL halo"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle_extract
+            g = grid.cpu().numpy()
+            c0 = time.perf_counter()
+            ov, of, _ = oracle_extract(g, thresh, lower, upper)
+            c1 = time.perf_counter()
+            assert ov.shape[0] == nv and of.shape[0] == nf, ("GPU/CPU count mismatch", ov.shape, of.shape, nv, nf)
+            line["cpu_baseline"] = {"value": round(nvox_total / (c1 - c0) / 1e6, 2), "unit": "Mvoxels/s", "cores": 1,
+                                    "kind": "port",
+                                    "sample": f"the same {rx}x{ry}x{rz} grid, one full extraction by oracle/mc_oracle.c "
+                                              f"({c1 - c0:.1f} s); host has {os.cpu_count()} cores"}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

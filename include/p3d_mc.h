@@ -86,11 +86,41 @@ int p3d_mc_emit(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz,
                 const p3d_mc_slab* slab, void* ws, float* vertices, int64_t cap_vertices,
                 int32_t* faces, int64_t cap_faces, int64_t* vertex_keys, void* stream);
 
+/* One-pass variant of count+emit for callers that can guess the output size (steady-state use: the
+ * same grid shape every frame).  Reads the field ONCE: classification, vertex ids and vertex
+ * emission happen in the same streaming kernel, faces follow from the sign bitfield.  At most
+ * cap_vertices / cap_faces rows are written; the true totals are always computed and are read with
+ * p3d_mc_read_counts afterwards.  If a total exceeds its capacity the caller allocates exact buffers
+ * and calls p3d_mc_emit on the same ws (no re-count needed: ids already assigned stay valid).
+ * cap_vertices = cap_faces = 0 makes this a pure count.  With slab->halo_last_plane the face pass
+ * is skipped (the caller imports the halo records first, then calls p3d_mc_emit with cap_vertices=0).
+ * Replaces the same reference code as p3d_mc_count + p3d_mc_emit (marching_cubes.cu:229-298). */
+int p3d_mc_extract_fused(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz, float thresh,
+                         const float lower[3], const float upper[3], const int64_t full_res[3],
+                         const p3d_mc_slab* slab, void* ws, float* vertices, int64_t cap_vertices,
+                         int32_t* faces, int64_t cap_faces, void* stream);
+
+/* Test hook: where the sign bitfield (u64 per 64-voxel unit, unit u = (x*ry+y)*ncz + c) and the
+ * vertex-id records ({u32 base, u32 offY | offZ<<16} per unit) live inside `ws`, so a test can
+ * rebuild the vertex-id -> edge-key map on the host and canonicalise a mesh (the reference has no
+ * counterpart; its ids live in vertex_grids, marching_cubes.cu:257-259). */
+int p3d_mc_debug_layout(int64_t rx, int64_t ry, int64_t rz, size_t* off_bits, size_t* off_records,
+                        int64_t* num_units, int32_t* chunks_per_row);
+
 /* Multi-GPU helpers: location and size of the per-plane vertex-id records inside `ws`, so the host
  * can ship the next rank's plane-0 records into this rank's halo plane (RCCL send/recv of
  * `bytes_per_plane` bytes).  plane is a local axis-0 index. */
 int p3d_mc_plane_records(void* ws, int64_t rx, int64_t ry, int64_t rz, int64_t plane,
                          void** records, size_t* bytes_per_plane);
+
+/* Measurement hooks (no reference counterpart; the reference's only instrumentation is the wall-clock
+ * Timer of prim3d/misc/utils.py:41-116).  mode 0 = off, 1 = hipEvents around the dominant kernel
+ * only, 2 = around every stage.  Events are recorded on the stream passed to count/emit.
+ * p3d_mc_profile_read synchronises those events and returns the per-stage durations (ms, -1 = not
+ * recorded) of the most recent count/emit pair; it returns the number of stages (8). */
+int p3d_mc_profile_enable(int mode);
+int p3d_mc_profile_read(float* stage_ms, int n);
+const char* p3d_mc_profile_stage_name(int stage);
 
 const char* p3d_last_error(void);
 int p3d_mc_abi_version(void);

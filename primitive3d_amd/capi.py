@@ -12,7 +12,8 @@ P3D_OK = 0
 
 # every symbol include/p3d_mc.h declares
 SYMBOLS = ("p3d_mc_abi_version", "p3d_last_error", "p3d_mc_workspace_bytes", "p3d_mc_count",
-           "p3d_mc_read_counts", "p3d_mc_emit", "p3d_mc_plane_records")
+           "p3d_mc_read_counts", "p3d_mc_emit", "p3d_mc_plane_records", "p3d_mc_profile_enable",
+           "p3d_mc_profile_read", "p3d_mc_profile_stage_name", "p3d_mc_extract_fused", "p3d_mc_debug_layout")
 
 
 class Slab(ctypes.Structure):
@@ -46,9 +47,18 @@ def lib():
                                   c_int64, c_void_p, c_int64, c_void_p, c_void_p]
         L.p3d_mc_plane_records.argtypes = [c_void_p, c_int64, c_int64, c_int64, c_int64, POINTER(c_void_p),
                                            POINTER(c_size_t)]
+        L.p3d_mc_extract_fused.argtypes = [c_void_p, c_int, c_int64, c_int64, c_int64, c_float, POINTER(c_float * 3),
+                                           POINTER(c_float * 3), POINTER(c_int64 * 3), POINTER(Slab), c_void_p,
+                                           c_void_p, c_int64, c_void_p, c_int64, c_void_p]
+        L.p3d_mc_debug_layout.argtypes = [c_int64, c_int64, c_int64, POINTER(c_size_t), POINTER(c_size_t),
+                                          POINTER(c_int64), POINTER(c_int32)]
+        L.p3d_mc_profile_enable.argtypes = [c_int]
+        L.p3d_mc_profile_read.argtypes = [POINTER(c_float), c_int]
+        L.p3d_mc_profile_stage_name.argtypes = [c_int]
+        L.p3d_mc_profile_stage_name.restype = c_char_p
         for name in SYMBOLS:
             getattr(L, name)  # raises AttributeError if the .so lacks a declared symbol
-            if name not in ("p3d_last_error",):
+            if name not in ("p3d_last_error", "p3d_mc_profile_stage_name"):
                 getattr(L, name).restype = getattr(L, name).restype or c_int
         _LIB = L
     return _LIB
@@ -109,6 +119,63 @@ def emit(grid, thresh, lower, upper, ws, vertices, faces, vertex_keys=None, slab
                              c_void_p(faces.data_ptr()) if capf else None, capf,
                              c_void_p(vertex_keys.data_ptr()) if vertex_keys is not None and capv else None,
                              _stream_ptr(grid)), "p3d_mc_emit")
+
+
+def profile_enable(mode: int):
+    _check(lib().p3d_mc_profile_enable(mode), "p3d_mc_profile_enable")
+
+
+def profile_read():
+    """{stage name: ms} for the stages recorded in the most recent count/emit pair."""
+    buf = (c_float * 8)()
+    n = lib().p3d_mc_profile_read(buf, 8)
+    if n < 0:
+        _check(n, "p3d_mc_profile_read")
+    return {lib().p3d_mc_profile_stage_name(i).decode(): buf[i] for i in range(n) if buf[i] >= 0}
+
+
+def extract_fused_raw(grid, thresh, lower, upper, ws, vertices, faces, slab=None, full_res=None):
+    """p3d_mc_extract_fused: one pass over the field, writes at most the capacities of the two buffers."""
+    rx, ry, rz = grid.shape
+    lo = (c_float * 3)(*[float(v) for v in lower])
+    up = (c_float * 3)(*[float(v) for v in upper])
+    fr = (c_int64 * 3)(*[int(v) for v in full_res]) if full_res is not None else None
+    capv = vertices.shape[0] if vertices is not None else 0
+    capf = faces.shape[0] if faces is not None else 0
+    _check(lib().p3d_mc_extract_fused(c_void_p(grid.data_ptr()), _dtype_code(grid), rx, ry, rz, c_float(thresh),
+                                      byref(lo), byref(up), byref(fr) if fr is not None else None,
+                                      byref(slab) if slab is not None else None, c_void_p(ws.data_ptr()),
+                                      c_void_p(vertices.data_ptr()) if capv else None, capv,
+                                      c_void_p(faces.data_ptr()) if capf else None, capf, _stream_ptr(grid)),
+           "p3d_mc_extract_fused")
+
+
+def debug_layout(rx, ry, rz):
+    ob, orr, nu, ncz = c_size_t(0), c_size_t(0), c_int64(0), c_int32(0)
+    _check(lib().p3d_mc_debug_layout(rx, ry, rz, byref(ob), byref(orr), byref(nu), byref(ncz)), "p3d_mc_debug_layout")
+    return {"off_bits": ob.value, "off_records": orr.value, "num_units": nu.value, "chunks_per_row": ncz.value}
+
+
+def extract_fused(grid, thresh, lower=None, upper=None, cap_vertices=None, cap_faces=None, return_ws=False):
+    """One-pass extraction with capacity guess + exact re-emit on overflow (what the pybind adapter does)."""
+    import torch
+    rx, ry, rz = grid.shape
+    lower = [0.0, 0.0, 0.0] if lower is None else lower
+    upper = [rx, ry, rz] if upper is None else upper
+    nvox = rx * ry * rz
+    capv = max(1024, nvox // 16) if cap_vertices is None else cap_vertices
+    capf = 2 * capv if cap_faces is None else cap_faces
+    ws = torch.empty(workspace_bytes(rx, ry, rz), dtype=torch.uint8, device=grid.device)
+    verts = torch.empty((capv, 3), dtype=torch.float32, device=grid.device)
+    faces = torch.empty((capf, 3), dtype=torch.int32, device=grid.device)
+    extract_fused_raw(grid, thresh, lower, upper, ws, verts, faces)
+    nv, nf = read_counts(ws)
+    if nv > capv or nf > capf:
+        verts = torch.empty((nv, 3), dtype=torch.float32, device=grid.device)
+        faces = torch.empty((nf, 3), dtype=torch.int32, device=grid.device)
+        emit(grid, thresh, lower, upper, ws, verts, faces)
+    out = (verts[:nv], faces[:nf])
+    return out + (ws,) if return_ws else out
 
 
 def plane_records(ws, rx, ry, rz, plane):

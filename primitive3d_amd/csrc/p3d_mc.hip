@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
@@ -120,11 +121,17 @@ __device__ inline void static_for(F&& f) {
     }
 }
 
-// w[lane J] = v (v wave-uniform).  The lane select must be an inline constant: on gfx9 a VOP3 may read
-// only one SGPR, and the value already is one.
+// (lo,hi)[lane J] = the two halves of the wave-uniform 64-bit mask m (a v_cmp result).
+//  * The lane select must be an inline constant: on gfx9 a VOP3 may read only one SGPR, and the value is one.
+//  * HAZARD (measured on gfx950, tools/ubench/writelane_hazard.hip): v_writelane_b32 that reads an SGPR or VCC
+//    written by the IMMEDIATELY preceding VALU instruction (the v_cmp) receives the register's OLD contents.
+//    One wait state is enough; the compiler cannot see into an asm statement, so the s_nop is in the string.
 template <int J>
-__device__ inline void write_lane(int& w, int v) {
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(w) : "s"(v), "n"(J));
+__device__ inline void write_lane2(int& lo, int& hi, u64 m) {
+    asm("s_nop 0\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+        : "+v"(lo), "+v"(hi)
+        : "s"((int)(u32)m), "s"((int)(u32)(m >> 32)), "n"(J)
+        : "vcc");
 }
 
 __device__ inline float load_f32(const float* p) { return *p; }
@@ -185,8 +192,7 @@ __global__ void __launch_bounds__(kBlock) k_classify(const T* __restrict__ grid,
             const float v = load_f32(grid + idx);
             const bool inside = (row < nrows) && (z < d.rz) && (v > thresh);
             const u64 m = __ballot(inside);
-            write_lane<j>(wlo, (int)(u32)m);
-            write_lane<j>(whi, (int)(u32)(m >> 32));
+            write_lane2<j>(wlo, whi, m);
             if (++c == d.ncz) {
                 c = 0;
                 ++row;
@@ -343,6 +349,8 @@ __global__ void __launch_bounds__(kBlock) k_emit_vertices(const T* __restrict__ 
         }
     }
 }
+
+#include "fused_stream.inc"
 
 // ---------------------------------------------------------------------------------------------
 // K4: faces from sign words + vertex-id records.  One block = 256 units of one x plane.
@@ -515,6 +523,7 @@ int fail(int code, const char* fmt, const char* detail = "") {
 
 int check_dims(int64_t rx, int64_t ry, int64_t rz) {
     if (rx < 1 || ry < 1 || rz < 1) return fail(P3D_EINVAL, "grid dims must be >= 1%s");
+    if (ry * rz >= (1ll << 29) || rz >= (1ll << 24)) return fail(P3D_ERANGE, "plane too large%s");
     const Dims d = make_dims(rx, ry, rz);
     // int32 vertex ids / 32-bit block bases: refuse grids whose worst case cannot be indexed safely
     if (d.U >= (1ll << 31) || rx * ry >= (1ll << 40)) return fail(P3D_ERANGE, "grid too large%s");
@@ -527,6 +536,34 @@ int grid_for(int64_t work_items, int per_block, int64_t cap) {
     if (g > cap) g = cap;
     return (int)g;
 }
+
+// ---- optional stage timing (bench/roofline): hipEvents recorded on the caller's stream ----------
+enum { ST_CLASSIFY = 0, ST_UNIT_COUNTS, ST_SCAN_V, ST_UNIT_RECORDS, ST_FACES_COUNT, ST_SCAN_F, ST_EMIT_VERTS,
+       ST_EMIT_FACES, ST_N };
+const char* const k_stage_names[ST_N] = {"k_classify",    "k_unit_counts", "k_scan_blocks(v)", "k_unit_records",
+                                         "k_faces<count>", "k_scan_blocks(f)", "k_emit_vertices", "k_faces<emit>"};
+int g_prof_mode = 0;  // 0 off, 1 dominant kernel only (k_classify), 2 every stage
+hipEvent_t g_ev[ST_N][2];
+bool g_ev_made = false;
+bool g_ev_used[ST_N];
+
+struct StageTimer {
+    int stage;
+    hipStream_t st;
+    bool on;
+    StageTimer(int stage_, hipStream_t st_) : stage(stage_), st(st_) {
+        on = g_prof_mode == 2 || (g_prof_mode == 1 && stage == ST_CLASSIFY);
+        if (on) {
+            hipEventRecord(g_ev[stage][0], st);
+        }
+    }
+    ~StageTimer() {
+        if (on) {
+            hipEventRecord(g_ev[stage][1], st);
+            g_ev_used[stage] = true;
+        }
+    }
+};
 
 template <typename T>
 int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3d_mc_slab* slab, char* ws,
@@ -541,17 +578,33 @@ int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3
 
     // classify: 64 units (16 KiB of fp32) per wave iteration; cap the grid and stride the rest
     const int64_t wave_iters = (d.U + 63) / 64;
-    hipLaunchKernelGGL(k_classify<T>, dim3(grid_for(wave_iters, kBlock / 64, 256 * 16)), dim3(kBlock), 0, st, grid,
-                       thresh, d, bits);
-    hipLaunchKernelGGL(k_unit_counts, dim3((u32)w.nb_v), dim3(kBlock), 0, st, bits, d, halo, cnt, bsv);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, bsv, bbv, w.nb_v, hdr + H_V);
-    hipLaunchKernelGGL(k_unit_records, dim3((u32)w.nb_v), dim3(kBlock), 0, st, cnt, bbv, d, halo, rec);
+    {
+        StageTimer tm(ST_CLASSIFY, st);
+        hipLaunchKernelGGL(k_classify<T>, dim3(grid_for(wave_iters, kBlock / 64, 256 * 16)), dim3(kBlock), 0, st,
+                           grid, thresh, d, bits);
+    }
+    {
+        StageTimer tm(ST_UNIT_COUNTS, st);
+        hipLaunchKernelGGL(k_unit_counts, dim3((u32)w.nb_v), dim3(kBlock), 0, st, bits, d, halo, cnt, bsv);
+    }
+    {
+        StageTimer tm(ST_SCAN_V, st);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, bsv, bbv, w.nb_v, hdr + H_V);
+    }
+    {
+        StageTimer tm(ST_UNIT_RECORDS, st);
+        hipLaunchKernelGGL(k_unit_records, dim3((u32)w.nb_v), dim3(kBlock), 0, st, cnt, bbv, d, halo, rec);
+    }
     if (w.nb_f > 0) {
+        StageTimer tm(ST_FACES_COUNT, st);
         FaceArgs a{halo, 0, 0, w.tpp};
         hipLaunchKernelGGL(k_faces<false>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, bbf, bsf,
                            (int32_t*)nullptr, (int64_t)0);
     }
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, bsf, bbf, w.nb_f, hdr + H_T);
+    {
+        StageTimer tm(ST_SCAN_F, st);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, bsf, bbf, w.nb_f, hdr + H_T);
+    }
     HIP_TRY(hipGetLastError());
     return P3D_OK;
 }
@@ -564,11 +617,96 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
     uint2* rec = (uint2*)(ws + w.rec);
     u32* cnt = (u32*)(ws + w.cnt);
     u32 *bsf = (u32*)(ws + w.bsum_f), *bbf = (u32*)(ws + w.bbase_f);
-    if (capv > 0)
+    if (capv > 0) {
+        // per-unit crossing counts select the units to visit; recomputed here (12 us at 512^3) because the
+        // fused streaming kernel does not materialise them
+        hipLaunchKernelGGL(k_unit_counts, dim3((u32)w.nb_v), dim3(kBlock), 0, st, bits, d, halo, cnt,
+                           (u32*)(ws + w.bsum_v));
+        StageTimer tm(ST_EMIT_VERTS, st);
         hipLaunchKernelGGL(k_emit_vertices<T>, dim3(grid_for(d.U, kBlock / 64, 256 * 32)), dim3(kBlock), 0, st, grid,
                            thresh, d, bits, cnt, rec, t, slab ? slab->x_origin : (int64_t)0, verts, capv, keys);
+    }
     if (w.nb_f > 0 && capf > 0) {
+        StageTimer tm(ST_EMIT_FACES, st);
         FaceArgs a{halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0, w.tpp};
+        hipLaunchKernelGGL(k_faces<true>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, bbf, bsf, faces,
+                           capf);
+    }
+    HIP_TRY(hipGetLastError());
+    return P3D_OK;
+}
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+template <typename T, int NC, int RY>
+void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xform& t, int64_t x_origin, u64* bits,
+                  uint2* rec, u64* cursor, float* verts, int64_t capv, hipStream_t st) {
+    FusedGeom g;
+    g.nzt = (d.ncz + NC - 1) / NC;
+    g.nyt = (int)((d.ry + 4 * RY - 1) / (4 * RY));
+    // enough blocks to fill the chip a few times over, but planes per block >= 8 (x-halo overhead 1/XT)
+    const int64_t per_slab = (int64_t)g.nzt * g.nyt;
+    int64_t want_slabs = (env_int("P3D_FUSED_BLOCKS", 4096) + per_slab - 1) / per_slab;
+    int xt = (int)((d.rx + want_slabs - 1) / want_slabs);
+    xt = env_int("P3D_FUSED_XT", xt < 8 ? 8 : xt);
+    if (xt > d.rx) xt = (int)d.rx;
+    g.XT = xt;
+    g.nxt = (int)((d.rx + xt - 1) / xt);
+    const int64_t nblocks = per_slab * g.nxt;
+    hipLaunchKernelGGL((k_fused<T, NC, RY, 3072>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, grid, thresh, d, g,
+                       halo, t, x_origin, bits, rec, cursor, verts, capv);
+}
+
+template <typename T>
+void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xform& t, int64_t x_origin, u64* bits,
+                    uint2* rec, u64* cursor, float* verts, int64_t capv, hipStream_t st) {
+    // two tile geometries (both hold 32 unit words per wave-plane): long rows / short rows
+    if (d.ncz >= 3) launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursor, verts, capv, st);
+    else launch_fused<T, 2, 15>(grid, d, thresh, halo, t, x_origin, bits, rec, cursor, verts, capv, st);
+}
+
+Xform make_xform(const Dims& d, const float lower[3], const float upper[3], const int64_t full_res[3]) {
+    const int64_t fr[3] = {full_res ? full_res[0] : d.rx, full_res ? full_res[1] : d.ry, full_res ? full_res[2] : d.rz};
+    // marching_cubes.cu:293-297 verbatim, including the upper[2]-lower[1] term of :295 (fp32 arithmetic)
+    Xform t;
+    t.sx = (upper[0] - lower[0]) / static_cast<float>(fr[0]);
+    t.sy = (upper[2] - lower[1]) / static_cast<float>(fr[1]);
+    t.sz = (upper[2] - lower[2]) / static_cast<float>(fr[2]);
+    t.ox = lower[0];
+    t.oy = lower[1];
+    t.oz = lower[2];
+    return t;
+}
+
+template <typename T>
+int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xform& t, const p3d_mc_slab* slab,
+               char* ws, float* verts, int64_t capv, int32_t* faces, int64_t capf, hipStream_t st) {
+    const int halo = slab ? slab->halo_last_plane : 0;
+    u64* hdr = (u64*)(ws + w.hdr);
+    u64* bits = (u64*)(ws + w.bits);
+    uint2* rec = (uint2*)(ws + w.rec);
+    u32 *bsf = (u32*)(ws + w.bsum_f), *bbf = (u32*)(ws + w.bbase_f);
+    HIP_TRY(hipMemsetAsync(hdr, 0, kHdrBytes, st));
+    {
+        StageTimer tm(ST_CLASSIFY, st);
+        const int64_t xo = slab ? slab->x_origin : 0;
+        dispatch_fused<T>(grid, d, thresh, halo, t, xo, bits, rec, hdr + H_V, verts, capv, st);
+    }
+    FaceArgs a{halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0, w.tpp};
+    if (w.nb_f > 0) {
+        StageTimer tm(ST_FACES_COUNT, st);
+        hipLaunchKernelGGL(k_faces<false>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, bbf, bsf,
+                           (int32_t*)nullptr, (int64_t)0);
+    }
+    {
+        StageTimer tm(ST_SCAN_F, st);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, bsf, bbf, w.nb_f, hdr + H_T);
+    }
+    if (w.nb_f > 0 && capf > 0 && !(slab && slab->halo_last_plane)) {
+        StageTimer tm(ST_EMIT_FACES, st);
         hipLaunchKernelGGL(k_faces<true>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, bbf, bsf, faces,
                            capf);
     }
@@ -626,15 +764,7 @@ int p3d_mc_emit(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz,
     if (int rc = check_dims(rx, ry, rz)) return rc;
     const Dims d = make_dims(rx, ry, rz);
     const Ws w = make_ws(d);
-    const int64_t fr[3] = {full_res ? full_res[0] : rx, full_res ? full_res[1] : ry, full_res ? full_res[2] : rz};
-    // marching_cubes.cu:293-297 verbatim, including the upper[2]-lower[1] term of :295 (fp32 arithmetic)
-    Xform t;
-    t.sx = (upper[0] - lower[0]) / static_cast<float>(fr[0]);
-    t.sy = (upper[2] - lower[1]) / static_cast<float>(fr[1]);
-    t.sz = (upper[2] - lower[2]) / static_cast<float>(fr[2]);
-    t.ox = lower[0];
-    t.oy = lower[1];
-    t.oz = lower[2];
+    const Xform t = make_xform(d, lower, upper, full_res);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == P3D_F32)
         return emit_impl((const float*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices, faces,
@@ -644,6 +774,66 @@ int p3d_mc_emit(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz,
                          cap_faces, vertex_keys, st);
     return fail(P3D_EINVAL, "unknown dtype%s");
 }
+
+int p3d_mc_extract_fused(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz, float thresh,
+                         const float lower[3], const float upper[3], const int64_t full_res[3],
+                         const p3d_mc_slab* slab, void* ws, float* vertices, int64_t cap_vertices, int32_t* faces,
+                         int64_t cap_faces, void* stream) {
+    if (!grid || !ws || !lower || !upper) return fail(P3D_EINVAL, "null pointer%s");
+    if ((cap_vertices > 0 && !vertices) || (cap_faces > 0 && !faces)) return fail(P3D_EINVAL, "null output%s");
+    if (cap_vertices < 0 || cap_faces < 0) return fail(P3D_EINVAL, "negative capacity%s");
+    if (int rc = check_dims(rx, ry, rz)) return rc;
+    const Dims d = make_dims(rx, ry, rz);
+    const Ws w = make_ws(d);
+    const Xform t = make_xform(d, lower, upper, full_res);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == P3D_F32)
+        return fused_impl((const float*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices, faces,
+                          cap_faces, st);
+    if (dtype == P3D_F16)
+        return fused_impl((const __half*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices, faces,
+                          cap_faces, st);
+    return fail(P3D_EINVAL, "unknown dtype%s");
+}
+
+int p3d_mc_debug_layout(int64_t rx, int64_t ry, int64_t rz, size_t* off_bits, size_t* off_records,
+                        int64_t* num_units, int32_t* chunks_per_row) {
+    if (!off_bits || !off_records || !num_units || !chunks_per_row) return fail(P3D_EINVAL, "null pointer%s");
+    if (int rc = check_dims(rx, ry, rz)) return rc;
+    const Dims d = make_dims(rx, ry, rz);
+    const Ws w = make_ws(d);
+    *off_bits = w.bits;
+    *off_records = w.rec;
+    *num_units = d.U;
+    *chunks_per_row = d.ncz;
+    return P3D_OK;
+}
+
+int p3d_mc_profile_enable(int mode) {
+    if (mode < 0 || mode > 2) return fail(P3D_EINVAL, "profile mode must be 0, 1 or 2%s");
+    if (mode && !g_ev_made) {
+        for (int i = 0; i < ST_N; ++i)
+            for (int j = 0; j < 2; ++j) HIP_TRY(hipEventCreate(&g_ev[i][j]));
+        g_ev_made = true;
+    }
+    for (int i = 0; i < ST_N; ++i) g_ev_used[i] = false;
+    g_prof_mode = mode;
+    return P3D_OK;
+}
+
+int p3d_mc_profile_read(float* stage_ms, int n) {
+    if (!stage_ms || n < ST_N) return fail(P3D_EINVAL, "need room for 8 stages%s");
+    for (int i = 0; i < ST_N; ++i) {
+        stage_ms[i] = -1.f;
+        if (g_ev_made && g_ev_used[i]) {
+            HIP_TRY(hipEventSynchronize(g_ev[i][1]));
+            HIP_TRY(hipEventElapsedTime(&stage_ms[i], g_ev[i][0], g_ev[i][1]));
+        }
+    }
+    return ST_N;
+}
+
+const char* p3d_mc_profile_stage_name(int stage) { return (stage >= 0 && stage < ST_N) ? k_stage_names[stage] : ""; }
 
 int p3d_mc_plane_records(void* ws, int64_t rx, int64_t ry, int64_t rz, int64_t plane, void** records,
                          size_t* bytes_per_plane) {

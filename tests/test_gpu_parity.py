@@ -21,6 +21,17 @@ def _hip_extract(gpu, g, thresh, lower, upper, dtype=torch.float32):
     return v.cpu().numpy(), f.cpu().numpy(), k.cpu().numpy()
 
 
+def _hip_extract_fused(gpu, g, thresh, lower, upper, dtype=torch.float32, **caps):
+    """One-pass kernel; vertex keys rebuilt on the host from the workspace (tests/ws_keys.py)."""
+    from primitive3d_amd import capi
+    from tests.ws_keys import vertex_keys_from_workspace
+    t = torch.from_numpy(np.ascontiguousarray(g)).to(gpu).to(dtype)
+    v, f, ws = capi.extract_fused(t, thresh, lower, upper, return_ws=True, **caps)
+    torch.cuda.synchronize()
+    keys = vertex_keys_from_workspace(ws.cpu().numpy(), t.shape, v.shape[0], capi.debug_layout(*t.shape))
+    return v.cpu().numpy(), f.cpu().numpy(), keys
+
+
 def _assert_same_mesh(hip, ref):
     hk, hv, hf = canonical_mesh(*hip)
     rk, rv, rf = canonical_mesh(*ref)
@@ -43,6 +54,52 @@ def test_small_cases_match_oracle(gpu, name):
     # ids are a permutation-free dense range
     if hip[1].size:
         assert hip[1].min() >= 0 and hip[1].max() < hip[0].shape[0]
+
+
+@pytest.mark.parametrize("name", sorted(small_cases().keys()))
+def test_small_cases_fused_match_oracle(gpu, name):
+    g, thresh, lower, upper = small_cases()[name]
+    hip = _hip_extract_fused(gpu, g, thresh, lower, upper)
+    ref = oracle_extract(g, thresh, lower, upper)
+    _assert_same_mesh(hip, ref)
+
+
+def test_fused_capacity_overflow_falls_back_to_exact_emit(gpu):
+    g, thresh, lower, upper = small_cases()["noise_33x17x200"]
+    hip = _hip_extract_fused(gpu, g, thresh, lower, upper, cap_vertices=100, cap_faces=50)
+    _assert_same_mesh(hip, oracle_extract(g, thresh, lower, upper))
+
+
+def test_fused_dense_noise_exercises_direct_path(gpu):
+    """White noise makes >1000 vertices per block-plane: LDS stage overflows, waves write directly."""
+    g = np.random.default_rng(77).standard_normal((24, 40, 512)).astype(np.float32)
+    hip = _hip_extract_fused(gpu, g, 0.0, None, None)
+    _assert_same_mesh(hip, oracle_extract(g, 0.0))
+
+
+def test_fused_wide_rows_need_z_halo(gpu):
+    """rz > 512: two z tiles per row, the tile seam goes through the z-halo voxel."""
+    from primitive3d_amd.fields import perlin_grid
+    g = perlin_grid((12, 10, 1100), period=16, seed=9).numpy()
+    hip = _hip_extract_fused(gpu, g, 0.0, None, None)
+    _assert_same_mesh(hip, oracle_extract(g, 0.0))
+    g = np.random.default_rng(5).standard_normal((6, 7, 1030)).astype(np.float32)
+    hip = _hip_extract_fused(gpu, g, 0.1, None, None)
+    _assert_same_mesh(hip, oracle_extract(g, 0.1))
+
+
+def test_fused_fp16(gpu):
+    g = small_cases()["perlin48"][0].astype(np.float16)
+    hip = _hip_extract_fused(gpu, g, 0.0, None, None, dtype=torch.float16)
+    _assert_same_mesh(hip, oracle_extract(g.astype(np.float32), 0.0))
+
+
+def test_fused_medium_perlin_192(gpu):
+    from primitive3d_amd.fields import perlin_grid
+    g = perlin_grid(192).numpy()
+    hip = _hip_extract_fused(gpu, g, 0.0, None, None)
+    assert hip[0].shape[0] == 268980 and hip[1].shape[0] == 531431
+    _assert_same_mesh(hip, oracle_extract(g, 0.0))
 
 
 def test_pybind_module_matches_oracle(gpu, built):

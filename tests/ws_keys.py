@@ -1,0 +1,49 @@
+"""Rebuild the vertex-id -> edge-key map of a HIP extraction on the host from the workspace's sign
+bitfield and vertex-id records (include/p3d_mc.h: p3d_mc_debug_layout), so meshes produced by the
+one-pass kernel (whose vertex order is chunk arrival order) can be put in canonical form.  Also
+checks the records themselves: every id in [0, V) must be assigned exactly once."""
+import numpy as np
+
+
+def vertex_keys_from_workspace(ws: np.ndarray, shape, nv: int, layout: dict) -> np.ndarray:
+    rx, ry, rz = shape
+    ncz, U = layout["chunks_per_row"], layout["num_units"]
+    assert U == rx * ry * ncz
+    bits = ws[layout["off_bits"]:layout["off_bits"] + U * 8].view(np.uint64).reshape(rx, ry, ncz)
+    rec = ws[layout["off_records"]:layout["off_records"] + U * 8].view(np.uint32).reshape(rx, ry, ncz, 2)
+    inside = np.unpackbits(bits.view(np.uint8).reshape(rx, ry, ncz * 8), axis=-1, bitorder="little").astype(bool)
+    assert not inside[:, :, rz:].any(), "sign bits beyond rz must be zero"
+    zpad = ncz * 64
+    valid = np.zeros((rx, ry, zpad), bool)
+    valid[:, :, :rz] = True
+    cx = np.zeros((rx, ry, zpad), bool)
+    cy = np.zeros_like(cx)
+    cz = np.zeros_like(cx)
+    cx[:-1] = (inside[:-1] != inside[1:]) & valid[:-1]
+    cy[:, :-1] = (inside[:, :-1] != inside[:, 1:]) & valid[:, :-1]
+    cz[:, :, :rz - 1] = inside[:, :, :rz - 1] != inside[:, :, 1:rz]
+    keys = np.full((nv,), -1, dtype=np.int64)
+    lin = (np.arange(rx)[:, None, None] * ry + np.arange(ry)[None, :, None]) * rz + np.arange(zpad)[None, None, :]
+    base = rec[..., 0].astype(np.int64)
+    offy = (rec[..., 1] & 0xFFFF).astype(np.int64)
+    offz = (rec[..., 1] >> 16).astype(np.int64)
+    for axis, (cr, off) in enumerate(((cx, None), (cy, offy), (cz, offz))):
+        cu = cr.reshape(rx, ry, ncz, 64)
+        rank = np.cumsum(cu, axis=-1) - cu
+        vid = base[..., None] + rank + (0 if off is None else off[..., None])
+        sel = cu
+        v = vid[sel]
+        k = lin.reshape(rx, ry, ncz, 64)[sel] * 3 + axis
+        assert v.size == 0 or (v.min() >= 0 and v.max() < nv), (axis, v.min() if v.size else None, nv)
+        assert (keys[v] == -1).all(), "vertex id assigned twice"
+        keys[v] = k
+        # the packed offsets must equal the crossing counts that precede the axis group
+        nx = cx.reshape(rx, ry, ncz, 64).sum(-1)
+        ny = cy.reshape(rx, ry, ncz, 64).sum(-1)
+        has = cu.any(-1)
+        if axis == 1:
+            assert (offy[has] == nx[has]).all()
+        if axis == 2:
+            assert (offz[has] == (nx + ny)[has]).all()
+    assert (keys >= 0).all(), "some vertex id has no owning edge"
+    return keys
