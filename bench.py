@@ -98,7 +98,7 @@ def main():
     for _ in range(args.steps):
         out = step()
         st = capi.profile_read()  # events of kernels that already finished (the host read V,F after them)
-        dom_ms.append(st.get("k_classify", float("nan")))
+        dom_ms.append(st.get("k_fused", st.get("k_classify", float("nan"))))
         for k, v in st.items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
     torch.cuda.synchronize()
@@ -131,10 +131,10 @@ def main():
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get("k_classify_hbm_bytes_per_launch")
+                traffic = json.loads(tfile.read_text()).get("k_fused_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_classify", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        roofline = {"bound": "hbm", "kernel": "k_fused", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_kernel_ms": round(avg_ms, 4), "alg_bytes_per_launch": alg_bytes,
                     "whole_call_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}

@@ -26,7 +26,8 @@ def _stale(out: Path, deps) -> bool:
 
 
 def capi_path() -> Path:
-    return PKG / "libp3dmc.so"
+    override = os.environ.get("P3D_CAPI_LIB")  # dev: try an alternative build of the C-ABI library
+    return Path(override) if override else PKG / "libp3dmc.so"
 
 
 def pybind_path() -> Path:
@@ -39,7 +40,7 @@ def build_capi(force: bool = False, verbose: bool = False) -> Path:
     if force or _stale(out, deps):
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
                # the reference epilogue is mul-then-add, never an FMA (marching_cubes.cu:298)
-               "-ffp-contract=off", "-Wall", "-Wextra",
+               "-ffp-contract=off", "-Wall", "-Wextra", "-DP3D_FUSED_CAP=1024", "-DP3D_FUSED_WAVES_PER_EU=4",
                str(CSRC / "p3d_mc.hip"), "-o", str(out)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

@@ -127,8 +127,8 @@ def profile_enable(mode: int):
 
 def profile_read():
     """{stage name: ms} for the stages recorded in the most recent count/emit pair."""
-    buf = (c_float * 8)()
-    n = lib().p3d_mc_profile_read(buf, 8)
+    buf = (c_float * 16)()
+    n = lib().p3d_mc_profile_read(buf, 16)
     if n < 0:
         _check(n, "p3d_mc_profile_read")
     return {lib().p3d_mc_profile_stage_name(i).decode(): buf[i] for i in range(n) if buf[i] >= 0}

@@ -6,7 +6,13 @@
 #include <c10/hip/HIPStream.h>
 #include <torch/extension.h>
 
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <fstream>
 #include <iostream>
 #include <stdexcept>
@@ -19,6 +25,11 @@ namespace py = pybind11;
 using torch::Tensor;
 
 namespace {
+
+// output-size hints of the one-pass path, per (device, grid shape)
+using CapKey = std::tuple<int, int64_t, int64_t, int64_t>;
+std::map<CapKey, std::pair<int64_t, int64_t>> g_cap_hint;
+std::mutex g_cap_mu;
 
 void check_rc(int rc, const char* what) {
     TORCH_CHECK(rc == P3D_OK, what, " failed (", rc, "): ", p3d_last_error());
@@ -46,18 +57,68 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     size_t ws_bytes = 0;
     check_rc(p3d_mc_workspace_bytes(rx, ry, rz, &ws_bytes), "p3d_mc_workspace_bytes");
     Tensor ws = torch::empty({(int64_t)ws_bytes}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
-
-    check_rc(p3d_mc_count(density_grid.data_ptr<float>(), P3D_F32, rx, ry, rz, thresh, nullptr, ws.data_ptr(), stream),
-             "p3d_mc_count");
+    const auto vopt = torch::TensorOptions().dtype(torch::kFloat).device(dev);
+    const auto fopt = torch::TensorOptions().dtype(torch::kInt).device(dev);
+    const float* grid = density_grid.data_ptr<float>();
+    Tensor vertices, faces;
     int64_t nv = 0, nf = 0;
-    check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, stream), "p3d_mc_read_counts");
 
-    Tensor vertices = torch::empty({nv, 3}, torch::TensorOptions().dtype(torch::kFloat).device(dev));
-    Tensor faces = torch::empty({nf, 3}, torch::TensorOptions().dtype(torch::kInt).device(dev));
-    check_rc(p3d_mc_emit(density_grid.data_ptr<float>(), P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(),
-                         nullptr, nullptr, ws.data_ptr(), nv ? vertices.data_ptr<float>() : nullptr, nv,
-                         nf ? faces.data_ptr<int32_t>() : nullptr, nf, nullptr, stream),
-             "p3d_mc_emit");
+    static const bool exact_mode = [] {
+        const char* m = std::getenv("P3D_MC_MODE");
+        return m && std::string(m) == "exact";
+    }();
+    if (exact_mode) {
+        // two-phase: count (reads the field), host sync, exact allocation, emit (reads the active part again)
+        check_rc(p3d_mc_count(grid, P3D_F32, rx, ry, rz, thresh, nullptr, ws.data_ptr(), stream), "p3d_mc_count");
+        check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, stream), "p3d_mc_read_counts");
+        vertices = torch::empty({nv, 3}, vopt);
+        faces = torch::empty({nf, 3}, fopt);
+        check_rc(p3d_mc_emit(grid, P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, nullptr,
+                             ws.data_ptr(), nv ? vertices.data_ptr<float>() : nullptr, nv,
+                             nf ? faces.data_ptr<int32_t>() : nullptr, nf, nullptr, stream),
+                 "p3d_mc_emit");
+        return {vertices, faces};
+    }
+
+    // one-pass: the field is streamed ONCE into output buffers sized from the last call on a grid of this
+    // shape (or from a density guess the first time); the true counts come back with the data.  If the guess
+    // was too small the ids already assigned stay valid and only the emission is redone into exact buffers.
+    const CapKey key{dev.index(), rx, ry, rz};
+    int64_t capv, capf;
+    {
+        std::lock_guard<std::mutex> g(g_cap_mu);
+        auto it = g_cap_hint.find(key);
+        if (it != g_cap_hint.end()) {
+            capv = it->second.first + it->second.first / 8 + 4096;
+            capf = it->second.second + it->second.second / 8 + 4096;
+        } else {
+            capv = std::max<int64_t>(4096, rx * ry * rz / 16);
+            capf = 2 * capv;
+        }
+    }
+    vertices = torch::empty({capv, 3}, vopt);
+    faces = torch::empty({capf, 3}, fopt);
+    check_rc(p3d_mc_extract_fused(grid, P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, nullptr,
+                                  ws.data_ptr(), vertices.data_ptr<float>(), capv, faces.data_ptr<int32_t>(), capf,
+                                  stream),
+             "p3d_mc_extract_fused");
+    check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, stream), "p3d_mc_read_counts");
+    {
+        std::lock_guard<std::mutex> g(g_cap_mu);
+        g_cap_hint[key] = {nv, nf};
+    }
+    if (nv > capv || nf > capf) {
+        vertices = torch::empty({nv, 3}, vopt);
+        faces = torch::empty({nf, 3}, fopt);
+        check_rc(p3d_mc_emit(grid, P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, nullptr,
+                             ws.data_ptr(), nv ? vertices.data_ptr<float>() : nullptr, nv,
+                             nf ? faces.data_ptr<int32_t>() : nullptr, nf, nullptr, stream),
+                 "p3d_mc_emit");
+        return {vertices, faces};
+    }
+    // exact-size results: a view when the buffer is mostly used, a copy when the guess was generous
+    vertices = (2 * nv >= capv) ? vertices.narrow(0, 0, nv) : vertices.narrow(0, 0, nv).clone();
+    faces = (2 * nf >= capf) ? faces.narrow(0, 0, nf) : faces.narrow(0, 0, nf).clone();
     return {vertices, faces};
 }
 

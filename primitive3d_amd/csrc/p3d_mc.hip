@@ -232,37 +232,35 @@ __global__ void __launch_bounds__(kBlock) k_unit_counts(const u64* __restrict__ 
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
 
-// exclusive scan of block sums by ONE block (nb is small: units/256 or face tiles)
+// exclusive scan of block sums by ONE block of 1024 threads: each thread owns a contiguous run
 __global__ void __launch_bounds__(1024) k_scan_blocks(const u32* __restrict__ bsum, u32* __restrict__ bbase,
                                                       int64_t nb, u64* __restrict__ total_out) {
     __shared__ u64 s_w[16];
-    __shared__ u64 s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (int64_t i0 = 0; i0 < nb; i0 += 1024) {
-        const int64_t i = i0 + tid;
-        const u64 v = (i < nb) ? bsum[i] : 0;
-        u64 inc = v;
+    const int64_t per = (nb + 1023) / 1024;
+    const int64_t i0 = (int64_t)tid * per, i1 = (i0 + per < nb) ? i0 + per : nb;
+    u64 sum = 0;
+    for (int64_t i = i0; i < i1; ++i) sum += bsum[i];
+    u64 inc = sum;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            u64 t = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t;
-        }
-        if (lane == 63) s_w[wave] = inc;
-        __syncthreads();
-        u64 wbase = 0;
-        for (int w = 0; w < wave; ++w) wbase += s_w[w];
-        const u64 carry = s_carry;
-        if (i < nb) {
-            const u64 e = carry + wbase + inc - v;
-            bbase[i] = (u32)(e > 0xffffffffull ? 0xffffffffull : e);
-        }
-        __syncthreads();
-        if (tid == 1023) s_carry = carry + wbase + inc;
-        __syncthreads();
+    for (int o = 1; o < 64; o <<= 1) {
+        const u64 t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
     }
-    if (tid == 0) *total_out = s_carry;
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    u64 wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) wbase += s_w[w];
+        total += s_w[w];
+    }
+    u64 run = wbase + inc - sum;
+    for (int64_t i = i0; i < i1; ++i) {
+        bbase[i] = (u32)(run > 0xffffffffull ? 0xffffffffull : run);
+        run += bsum[i];
+    }
+    if (tid == 0) *total_out = total;
 }
 
 // per-unit vertex-id records from counts + scanned block bases
@@ -387,6 +385,37 @@ __device__ inline void edge_owner(int e, int& col, int& dz, int& axis) {
     axis = v >> 3;
 }
 
+// vertex id of cell edge e (Bourke numbering, marching_cubes.cu:178-192) for the cell at (unit tu of the
+// tile, bit z): owner unit + rank of the edge among that unit's crossings of the same axis.
+// s_r[t][col] caches rec of the 4 owner columns at the cell's own chunk; the next chunk's record (edge at
+// bit 64 = bit 0 of unit+1) is the neighbouring tile entry when that is the same row, else a global load.
+__device__ inline int64_t edge_vertex_id(int e, const u64 (*s_w)[8], const uint2 (*s_r)[4], int tu, int z, int c,
+                                         int ncz, const int64_t* ucol, const uint2* __restrict__ rec, bool xhalo,
+                                         const FaceArgs& a) {
+    int col, dz, axis;
+    edge_owner(e, col, dz, axis);
+    const int zz = z + dz;
+    u32 rank;
+    uint2 r;
+    if (zz == 64) {  // first voxel of the next chunk: nothing below it
+        rank = 0;
+        r = (tu + 1 < kBlock && c + 1 < ncz) ? s_r[tu + 1][col] : rec[ucol[col] + 1];
+    } else {
+        const u64 W = s_w[tu][col];
+        u64 C;
+        if (axis == 2) C = W ^ s_w[tu][4 + col];
+        else if (axis == 0) C = W ^ s_w[tu][col == 0 ? 1 : 2];  // col 0 -> (x+1,y) ; col 3 -> (x+1,y+1)
+        else C = W ^ s_w[tu][col == 0 ? 3 : 2];                 // col 0 -> (x,y+1) ; col 1 -> (x+1,y+1)
+        rank = (u32)popc64(C & below(zz));
+        r = s_r[tu][col];
+    }
+    const u32 offa = axis == 0 ? 0u : (axis == 1 ? (r.y & 0xffffu) : (r.y >> 16));
+    const bool in_halo = xhalo && (col == 1 || col == 2);
+    return (int64_t)r.x + offa + rank + (in_halo ? a.halo_vid_base : a.vid_base);
+}
+
+constexpr int kCellCap = 4096;  // active cells expanded at a time (a 256-unit tile has up to 16384)
+
 template <bool EMIT>
 __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, const uint2* __restrict__ rec, Dims d,
                                                   FaceArgs a, const u32* __restrict__ bbase, u32* __restrict__ bsum,
@@ -394,7 +423,10 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     __shared__ u64 s_tab[256];
     __shared__ unsigned char s_ntri[256];
     __shared__ u64 s_w[kBlock][8];  // W00,W10,W11,W01 then their z+1 shifts: bit k of word j = corner j of cell k
-    __shared__ unsigned short s_cells[kBlock * 64];
+    __shared__ uint2 s_r[EMIT ? kBlock : 1][4];      // EMIT: vertex-id records of the 4 owner columns
+    __shared__ unsigned short s_cells[kCellCap];     // active cells of the current round: unit-in-tile << 6 | z
+    __shared__ unsigned char s_cmask[kBlock];        // EMIT: corner mask of the batch's cells
+    __shared__ unsigned short s_tri[kBlock * 5];     // EMIT: triangle -> cell-in-batch << 3 | slot
     __shared__ u32 s_tmp[4];
 
     const int tid = threadIdx.x;
@@ -410,7 +442,8 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     const int64_t u = x * d.P + p;
     const bool valid = (p < d.P) && (y + 1 < d.ry);  // x+1 < rx by grid construction
 
-    u64 act = 0;
+    // phase A (lane = unit): 2x2 column words, their z+1 shifts, active-cell word
+    u64 act_all = 0;
     if (valid) {
         const int64_t uc[4] = {u, u + d.P, u + d.P + d.ncz, u + d.ncz};
         u64 orr = 0, andd = ~0ull;
@@ -422,86 +455,85 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
             const u64 S = (W >> 1) | (nb << 63);
             s_w[tid][k] = W;
             s_w[tid][4 + k] = S;
+            if (EMIT) s_r[tid][k] = rec[uc[k]];  // only entries of units that own vertices are meaningful
             orr |= W | S;
             andd &= W & S;
         }
-        act = orr & ~andd & zedge(d, c);
+        act_all = orr & ~andd & zedge(d, c);
     }
-    u32 na_total;
-    u32 off = block_excl_scan((u32)popc64(act), s_tmp, &na_total);
-    while (act) {
-        const int z = __ffsll((long long)act) - 1;
-        act &= act - 1;
-        s_cells[off++] = (unsigned short)((tid << 6) | z);
-    }
-    __syncthreads();
 
-    // phase C: count triangles
-    u32 my_tris = 0;
-    for (u32 i = tid; i < na_total; i += kBlock) {
-        const int cell = s_cells[i];
+    auto cell_mask = [&](int cell) {
         const int t = cell >> 6, z = cell & 63;
         int mask = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) mask |= (int)((s_w[t][k] >> z) & 1ull) << k;
-        my_tris += s_ntri[mask];
-    }
-    const u32 tile_tris = block_reduce_sum(my_tris, s_tmp);
-    if (!EMIT) {
-        if (tid == 0) bsum[b] = tile_tris;
-        return;
-    }
-    if (tile_tris == 0) return;
+        return mask;
+    };
 
-    // EMIT sweep: batches of 256 cells, running offset kept in every thread
+    // the tile's cells are expanded into LDS in one round when they fit, else in four z-quarter rounds
+    u32 na_tile;
+    (void)block_excl_scan((u32)popc64(act_all), s_tmp, &na_tile);
+    const int rounds = na_tile <= (u32)kCellCap ? 1 : 4;
     const bool xhalo = a.halo_last && (x + 1 == d.rx - 1);  // columns 1,2 live in the imported plane
-    u32 run = bbase[b];
-    for (u32 i0 = 0; i0 < na_total; i0 += kBlock) {
-        const u32 i = i0 + tid;
-        int mask = 0, t = 0, z = 0;
-        if (i < na_total) {
-            const int cell = s_cells[i];
-            t = cell >> 6;
-            z = cell & 63;
+    u32 run = EMIT ? bbase[b] : 0u;
+    u32 my_tris = 0;
+
+    for (int rd = 0; rd < rounds; ++rd) {
+        u64 act = rounds == 1 ? act_all : (act_all & (0xffffull << (16 * rd)));
+        // phase B: dense list of active cells
+        u32 na_total;
+        u32 off = block_excl_scan((u32)popc64(act), s_tmp, &na_total);
+        while (act) {
+            const int z = __ffsll((long long)act) - 1;
+            act &= act - 1;
+            s_cells[off++] = (unsigned short)((tid << 6) | z);
+        }
+        __syncthreads();
+
+        if (!EMIT) {  // phase C (lane = active cell): triangle count
+            for (u32 i = tid; i < na_total; i += kBlock) my_tris += s_ntri[cell_mask(s_cells[i])];
+            continue;  // (next round's scan barriers order the reuse of s_cells)
+        }
+
+        // EMIT: batches of 256 cells; lane = cell assigns triangle slots, then lane = TRIANGLE writes 3 indices
+        // (12 contiguous bytes per lane, consecutive lanes contiguous: fully coalesced output)
+        for (u32 i0 = 0; i0 < na_total; i0 += kBlock) {
+            const u32 i = i0 + tid;
+            int mask = 0;
+            if (i < na_total) mask = cell_mask(s_cells[i]);
+            const u32 nt = s_ntri[mask];
+            u32 batch_total;
+            const u32 o = block_excl_scan(nt, s_tmp, &batch_total);  // (its barriers order the LDS reuse)
+            s_cmask[tid] = (unsigned char)mask;
+            for (u32 k = 0; k < nt; ++k) s_tri[o + k] = (unsigned short)((tid << 3) | k);
+            __syncthreads();
+            for (u32 tix = tid; tix < batch_total; tix += kBlock) {
+                const int ref = s_tri[tix];
+                const int ci = ref >> 3, k = ref & 7;
+                const int cell = s_cells[i0 + ci];
+                const int tu = cell >> 6, z = cell & 63;
+                const u64 row = s_tab[s_cmask[ci]];
+                const int64_t pt = tile * kBlock + tu;
+                const int cc = (int)(pt % d.ncz);
+                const int64_t pu = x * d.P + pt;
+                const int64_t ucol[4] = {pu, pu + d.P, pu + d.P + d.ncz, pu + d.ncz};
+                const int64_t f = (int64_t)run + tix;
+                if (f < cap_faces) {
+                    int32_t* o3 = faces + f * 3;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) mask |= (int)((s_w[t][k] >> z) & 1ull) << k;
-        }
-        const u32 nt = s_ntri[mask];
-        u32 batch_total;
-        const u32 o = block_excl_scan(nt, s_tmp, &batch_total);
-        if (nt) {
-            const int64_t pu = tile * kBlock + t;            // unit of this cell within the plane
-            const int64_t ucol[4] = {x * d.P + pu, x * d.P + pu + d.P, x * d.P + pu + d.P + d.ncz,
-                                     x * d.P + pu + d.ncz};
-            const u64 row = s_tab[mask];
-            const int64_t fbase = ((int64_t)run + o) * 3;
-            for (u32 k = 0; k < nt * 3; ++k) {
-                const int e = (int)((row >> (4 * k)) & 0xF);
-                int col, dz, axis;
-                edge_owner(e, col, dz, axis);
-                int zz = z + dz;
-                int64_t ou = ucol[col];
-                u32 rank;
-                if (zz == 64) {  // first voxel of the next chunk: no bits below it
-                    ou += 1;
-                    rank = 0;
-                } else {
-                    // crossing word of (col, axis) within this chunk
-                    u64 C;
-                    const u64 W = s_w[t][col];
-                    if (axis == 2) C = W ^ s_w[t][4 + col];
-                    else if (axis == 0) C = W ^ s_w[t][col == 0 ? 1 : 2];  // col 0 -> (x+1,y) ; col 3 -> (x+1,y+1)
-                    else C = W ^ s_w[t][col == 0 ? 3 : 2];                 // col 0 -> (x,y+1) ; col 1 -> (x+1,y+1)
-                    rank = (u32)popc64(C & below(zz));
+                    for (int q = 0; q < 3; ++q) {
+                        const int e = (int)((row >> (4 * (3 * k + q))) & 0xF);
+                        o3[q] = (int32_t)edge_vertex_id(e, s_w, s_r, tu, z, cc, d.ncz, ucol, rec, xhalo, a);
+                    }
                 }
-                const uint2 r = rec[ou];
-                const u32 offa = axis == 0 ? 0u : (axis == 1 ? (r.y & 0xffffu) : (r.y >> 16));
-                const bool in_halo = xhalo && (col == 1 || col == 2);
-                const int64_t vid = (int64_t)r.x + offa + rank + (in_halo ? a.halo_vid_base : a.vid_base);
-                if (fbase + k < cap_faces * 3) faces[fbase + k] = (int32_t)vid;
             }
+            run += batch_total;
+            __syncthreads();
         }
-        run += batch_total;
+    }
+    if (!EMIT) {
+        const u32 tile_tris = block_reduce_sum(my_tris, s_tmp);
+        if (tid == 0) bsum[b] = tile_tris;
     }
 }
 
@@ -539,9 +571,10 @@ int grid_for(int64_t work_items, int per_block, int64_t cap) {
 
 // ---- optional stage timing (bench/roofline): hipEvents recorded on the caller's stream ----------
 enum { ST_CLASSIFY = 0, ST_UNIT_COUNTS, ST_SCAN_V, ST_UNIT_RECORDS, ST_FACES_COUNT, ST_SCAN_F, ST_EMIT_VERTS,
-       ST_EMIT_FACES, ST_N };
+       ST_EMIT_FACES, ST_FUSED, ST_N };
 const char* const k_stage_names[ST_N] = {"k_classify",    "k_unit_counts", "k_scan_blocks(v)", "k_unit_records",
-                                         "k_faces<count>", "k_scan_blocks(f)", "k_emit_vertices", "k_faces<emit>"};
+                                         "k_faces<count>", "k_scan_blocks(f)", "k_emit_vertices", "k_faces<emit>",
+                                         "k_fused"};
 int g_prof_mode = 0;  // 0 off, 1 dominant kernel only (k_classify), 2 every stage
 hipEvent_t g_ev[ST_N][2];
 bool g_ev_made = false;
@@ -552,7 +585,7 @@ struct StageTimer {
     hipStream_t st;
     bool on;
     StageTimer(int stage_, hipStream_t st_) : stage(stage_), st(st_) {
-        on = g_prof_mode == 2 || (g_prof_mode == 1 && stage == ST_CLASSIFY);
+        on = g_prof_mode == 2 || (g_prof_mode == 1 && (stage == ST_CLASSIFY || stage == ST_FUSED));
         if (on) {
             hipEventRecord(g_ev[stage][0], st);
         }
@@ -646,7 +679,7 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
                   uint2* rec, u64* cursor, float* verts, int64_t capv, hipStream_t st) {
     FusedGeom g;
     g.nzt = (d.ncz + NC - 1) / NC;
-    g.nyt = (int)((d.ry + 4 * RY - 1) / (4 * RY));
+    g.nyt = (int)((d.ry + kFusedWPB * RY - 1) / (kFusedWPB * RY));
     // enough blocks to fill the chip a few times over, but planes per block >= 8 (x-halo overhead 1/XT)
     const int64_t per_slab = (int64_t)g.nzt * g.nyt;
     int64_t want_slabs = (env_int("P3D_FUSED_BLOCKS", 4096) + per_slab - 1) / per_slab;
@@ -656,7 +689,7 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
     g.XT = xt;
     g.nxt = (int)((d.rx + xt - 1) / xt);
     const int64_t nblocks = per_slab * g.nxt;
-    hipLaunchKernelGGL((k_fused<T, NC, RY, 3072>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, grid, thresh, d, g,
+    hipLaunchKernelGGL((k_fused<T, NC, RY, P3D_FUSED_CAP>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, grid, thresh, d, g,
                        halo, t, x_origin, bits, rec, cursor, verts, capv);
 }
 
@@ -691,7 +724,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     u32 *bsf = (u32*)(ws + w.bsum_f), *bbf = (u32*)(ws + w.bbase_f);
     HIP_TRY(hipMemsetAsync(hdr, 0, kHdrBytes, st));
     {
-        StageTimer tm(ST_CLASSIFY, st);
+        StageTimer tm(ST_FUSED, st);
         const int64_t xo = slab ? slab->x_origin : 0;
         dispatch_fused<T>(grid, d, thresh, halo, t, xo, bits, rec, hdr + H_V, verts, capv, st);
     }
@@ -822,7 +855,7 @@ int p3d_mc_profile_enable(int mode) {
 }
 
 int p3d_mc_profile_read(float* stage_ms, int n) {
-    if (!stage_ms || n < ST_N) return fail(P3D_EINVAL, "need room for 8 stages%s");
+    if (!stage_ms || n < ST_N) return fail(P3D_EINVAL, "need room for 9 stages%s");
     for (int i = 0; i < ST_N; ++i) {
         stage_ms[i] = -1.f;
         if (g_ev_made && g_ev_used[i]) {

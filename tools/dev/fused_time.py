@@ -1,0 +1,21 @@
+"""dev: time the one-pass kernel alone (through the C ABI) on the 512^3 Perlin grid."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+import torch
+from primitive3d_amd import capi
+from primitive3d_amd.fields import perlin_grid
+n = int(os.environ.get("N", "512"))
+g = perlin_grid(n, device="cuda")
+ws = torch.empty(capi.workspace_bytes(n, n, n), dtype=torch.uint8, device="cuda")
+capv = n ** 3 // 16
+v = torch.empty((capv, 3), device="cuda"); f = torch.empty((2 * capv, 3), dtype=torch.int32, device="cuda")
+capi.profile_enable(2)
+acc = {}
+for i in range(8):
+    capi.extract_fused_raw(g, 0.0, [0, 0, 0], [n, n, n], ws, v, f)
+    nv, nf = capi.read_counts(ws)
+    torch.cuda.synchronize()
+    st = capi.profile_read()
+    if i >= 3:
+        for k, t in st.items(): acc[k] = acc.get(k, 0) + t / 5
+print(os.environ.get("P3D_CAPI_LIB", "default"), "V", nv, "F", nf, {k: round(t * 1e3, 1) for k, t in acc.items()}, "us")
