@@ -1,0 +1,194 @@
+"""Axis-0 slab decomposition of one large volume across the GPUs of a node (SURVEY.md section 8e;
+new capability, the reference is single-GPU only).
+
+Rank r owns sample planes [x0, x1) of the [rx, ry, rz] grid and every cell whose lower corner lies in
+them.  The cells of its last layer need plane x1, which lives on rank r+1: ONE halo plane is
+received over RCCL (torch.distributed "nccl" backend = RCCL over xGMI, point-to-point send/recv,
+4 MiB at 1024^2 fp32).  Vertices on edges inside that halo plane are owned by rank r+1, so after the
+local single-pass extraction rank r+1 also ships the vertex-id records of its plane 0 (ry*ncz*8 B,
+128 KiB at 1024^2) and every rank learns the global vertex base of its neighbour from an
+all-gather of the per-rank counts.  No other collective touches the data path.
+
+    phase A   halo plane  r+1 -> r        (send/recv)
+    phase B   local one-pass extraction   (vertices final, faces counted)
+    phase C   counts all-gather; plane-0 records r+1 -> r
+    phase D   local face emission with global vertex ids
+
+The compute backend is pluggable so the orchestration can be tested without a GPU: `HipBackend`
+drives the C ABI (include/p3d_mc.h); tests inject a CPU stand-in built on the oracle.
+"""
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+
+def slab_bounds(rx: int, world: int) -> List[Tuple[int, int]]:
+    """[x0, x1) per rank, as even as possible; every rank gets at least one plane."""
+    assert world >= 1 and rx >= world, "need at least one plane per rank"
+    base, rem = divmod(rx, world)
+    out, x = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((x, x + n))
+        x += n
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# backends
+# ---------------------------------------------------------------------------------------------
+class HipBackend:
+    """Local extraction through the C ABI on the rank's own GPU."""
+
+    def __init__(self, device):
+        from . import capi
+        self.capi = capi
+        self.device = device
+        self._cap = None  # output-size hint from the previous call
+        self._ws = None
+
+    def count_and_vertices(self, grid, thresh, lower, upper, full_res, x_origin, halo):
+        c = self.capi
+        rx, ry, rz = grid.shape
+        nbytes = c.workspace_bytes(rx, ry, rz)
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        ws = self._ws
+        capv = self._cap if self._cap is not None else max(4096, rx * ry * rz // 16)
+        self._slab = c.Slab(1 if halo else 0, 0, 0, 0, x_origin)
+        verts = torch.empty((capv, 3), dtype=torch.float32, device=self.device)
+        c.extract_fused_raw(grid, thresh, lower, upper, ws, verts, None, slab=self._slab, full_res=full_res)
+        nv, nf = c.read_counts(ws)
+        if nv > capv:  # guess too small: ids stay valid, redo only the vertex emission into an exact buffer
+            verts = torch.empty((nv, 3), dtype=torch.float32, device=self.device)
+            c.emit(grid, thresh, lower, upper, ws, verts, None, slab=self._slab, full_res=full_res)
+        self._cap = nv + nv // 8 + 4096
+        self._state = (grid, thresh, lower, upper, full_res, ws, nf)
+        return nv, nf, verts[:nv]
+
+    def _plane_view(self, plane):
+        grid, ws = self._state[0], self._state[5]
+        ptr, nbytes = self.capi.plane_records(ws, *grid.shape, plane)
+        off = ptr - ws.data_ptr()
+        return ws[off:off + nbytes]
+
+    def export_first_plane_records(self):
+        return self._plane_view(0)
+
+    def halo_records_buffer(self):
+        return self._plane_view(self._state[0].shape[0] - 1)
+
+    def faces(self, vertex_id_base, halo_vertex_id_base):
+        grid, thresh, lower, upper, full_res, ws, nf = self._state
+        s = self._slab
+        slab = self.capi.Slab(s.halo_last_plane, 0, vertex_id_base, halo_vertex_id_base, s.x_origin)
+        faces = torch.empty((nf, 3), dtype=torch.int32, device=self.device)
+        self.capi.emit(grid, thresh, lower, upper, ws, None, faces, slab=slab, full_res=full_res)
+        return faces
+
+
+# ---------------------------------------------------------------------------------------------
+# orchestration
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class SlabResult:
+    vertices: torch.Tensor  # [V_r, 3] f32, already in bounding-box coordinates of the FULL grid
+    faces: torch.Tensor     # [F_r, 3] i32, GLOBAL vertex ids (vertices of all ranks concatenated in rank order)
+    vertex_base: int
+    counts: List[Tuple[int, int]]
+
+    def __iter__(self):  # (vertices, faces) unpacking like the single-GPU call
+        return iter((self.vertices, self.faces))
+
+
+class SlabExtractor:
+    def __init__(self, shape: Sequence[int], rank: int, world: int, device, dtype=torch.float32, backend=None):
+        self.shape = tuple(int(s) for s in shape)
+        self.rank, self.world = rank, world
+        self.device = device
+        self.x0, self.x1 = slab_bounds(self.shape[0], world)[rank]
+        self.n = self.x1 - self.x0
+        self.has_halo = rank < world - 1
+        rx, ry, rz = self.shape
+        self.grid = torch.empty((self.n + (1 if self.has_halo else 0), ry, rz), dtype=dtype, device=device)
+        self.backend = backend if backend is not None else HipBackend(device)
+
+    # -- data ---------------------------------------------------------------------------------
+    def fill_local(self, gen):
+        """gen(x0, x1) -> [x1-x0, ry, rz] tensor: the rank synthesises / loads only its own planes."""
+        self.grid[:self.n].copy_(gen(self.x0, self.x1))
+
+    # -- phases (the in-process test harness calls them in lock step) ---------------------------
+    def halo_send_buffer(self) -> Optional[torch.Tensor]:
+        return self.grid[0] if self.rank > 0 else None
+
+    def halo_recv_buffer(self) -> Optional[torch.Tensor]:
+        return self.grid[self.n] if self.has_halo else None
+
+    def phase_extract(self, thresh, lower, upper):
+        nv, nf, verts = self.backend.count_and_vertices(self.grid, float(thresh), list(lower), list(upper),
+                                                        self.shape, self.x0, self.has_halo)
+        self._nv, self._nf, self._verts = nv, nf, verts
+        return nv, nf
+
+    def records_send_buffer(self):
+        return self.backend.export_first_plane_records() if self.rank > 0 else None
+
+    def records_recv_buffer(self):
+        return self.backend.halo_records_buffer() if self.has_halo else None
+
+    def phase_faces(self, counts: List[Tuple[int, int]]) -> SlabResult:
+        base = sum(c[0] for c in counts[:self.rank])
+        total = sum(c[0] for c in counts)
+        if total > 2 ** 31 - 1:
+            raise OverflowError("global vertex count exceeds int32 face indices")
+        halo_base = base + counts[self.rank][0]
+        faces = self.backend.faces(base, halo_base)
+        return SlabResult(self._verts, faces, base, counts)
+
+    # -- the distributed call -----------------------------------------------------------------
+    def extract(self, thresh, lower=None, upper=None) -> SlabResult:
+        import torch.distributed as dist
+        rx, ry, rz = self.shape
+        lower = [0.0, 0.0, 0.0] if lower is None else lower
+        upper = [rx, ry, rz] if upper is None else upper
+
+        def shift_to_prev(send, recv):  # rank r sends to r-1, receives from r+1: nearest-neighbour only
+            ops = []
+            if send is not None:
+                ops.append(dist.P2POp(dist.isend, send, self.rank - 1))
+            if recv is not None:
+                ops.append(dist.P2POp(dist.irecv, recv, self.rank + 1))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+
+        shift_to_prev(self.halo_send_buffer(), self.halo_recv_buffer())
+        nv, nf = self.phase_extract(thresh, lower, upper)
+        mine = torch.tensor([nv, nf], dtype=torch.int64, device=self.grid.device)
+        allc = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(allc, mine)
+        counts = [(int(c[0]), int(c[1])) for c in torch.stack(allc).cpu()]
+        shift_to_prev(self.records_send_buffer(), self.records_recv_buffer())
+        return self.phase_faces(counts)
+
+
+def extract_in_process(grid_full: torch.Tensor, world: int, thresh, lower=None, upper=None, device=None,
+                       backend_factory=None) -> List[SlabResult]:
+    """Run all `world` ranks of the slab algorithm sequentially in ONE process (copies stand in for the
+    send/recv pairs).  Used to validate the multi-GPU path on a single device."""
+    device = grid_full.device if device is None else device
+    shape = tuple(grid_full.shape)
+    lower = [0.0, 0.0, 0.0] if lower is None else lower
+    upper = list(shape) if upper is None else upper
+    exs = [SlabExtractor(shape, r, world, device, dtype=grid_full.dtype,
+                         backend=backend_factory(r) if backend_factory else None) for r in range(world)]
+    for e in exs:
+        e.fill_local(lambda x0, x1: grid_full[x0:x1].to(device))
+    for r in range(world - 1):  # phase A
+        exs[r].halo_recv_buffer().copy_(exs[r + 1].halo_send_buffer())
+    counts = [e.phase_extract(thresh, lower, upper) for e in exs]  # phase B
+    for r in range(world - 1):  # phase C
+        exs[r].records_recv_buffer().copy_(exs[r + 1].records_send_buffer())
+    return [e.phase_faces(counts) for e in exs]  # phase D

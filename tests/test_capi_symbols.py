@@ -1,0 +1,43 @@
+"""The C-ABI library loads on a machine without a GPU and exports every function include/p3d_mc.h
+declares (no compute calls here)."""
+import ctypes
+import re
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def declared_functions():
+    text = (ROOT / "include" / "p3d_mc.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(p3d_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_functions_are_exported(built):
+    from primitive3d_amd import capi
+    from primitive3d_amd._build import capi_path
+    lib = ctypes.CDLL(str(capi_path()))
+    names = declared_functions()
+    assert "p3d_mc_extract_fused" in names and "p3d_mc_count" in names and len(names) >= 11
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/p3d_mc.h but not exported"
+    assert sorted(capi.SYMBOLS) == names, "capi.py binds exactly the declared entry points"
+
+
+def test_host_only_entry_points(built):
+    from primitive3d_amd import capi
+    assert capi.lib().p3d_mc_abi_version() == 1
+    n512 = capi.workspace_bytes(512, 512, 512)
+    assert 0.25 * 512 ** 3 < n512 < 0.40 * 512 ** 3  # bits + records + counts: ~0.3 B/voxel (reference: 12 B/voxel)
+    lay = capi.debug_layout(10, 9, 66)
+    assert lay["chunks_per_row"] == 2 and lay["num_units"] == 10 * 9 * 2
+    import pytest
+    with pytest.raises(capi.P3DError):
+        capi.workspace_bytes(0, 4, 4)
+
+
+def test_product_path_has_no_cpu_fallback():
+    """The package must not import the oracle or route compute to the CPU."""
+    for p in (ROOT / "primitive3d_amd").glob("*.py"):
+        src = p.read_text()
+        assert "import oracle" not in src and "from oracle" not in src, p

@@ -1,0 +1,56 @@
+"""Multi-GPU slab path validated on ONE device: all ranks of the algorithm run sequentially in one
+process (primitive3d_amd.slab.extract_in_process), tensor copies standing in for the RCCL send/recv
+pairs.  The merged mesh must equal the oracle's mesh of the whole grid."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import canonical_mesh, oracle_extract
+from tests.test_gpu_parity import _assert_same_mesh
+from tests.ws_keys import vertex_keys_from_workspace
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_slabs_merge_to_the_whole_grid_mesh(gpu, world):
+    from primitive3d_amd import capi
+    from primitive3d_amd.fields import perlin_grid
+    from primitive3d_amd.slab import SlabExtractor, slab_bounds
+    g = perlin_grid((37, 21, 150), period=12, seed=5).numpy()
+    thresh, lower, upper = 0.02, [0.5, -1.0, 2.0], [3.0, 4.0, 9.0]
+    full = torch.from_numpy(g).to(gpu)
+    shape = g.shape
+    exs = [SlabExtractor(shape, r, world, gpu) for r in range(world)]
+    for e in exs:
+        e.fill_local(lambda x0, x1: full[x0:x1])
+    for r in range(world - 1):
+        exs[r].halo_recv_buffer().copy_(exs[r + 1].halo_send_buffer())
+    counts = [e.phase_extract(thresh, lower, upper) for e in exs]
+    for r in range(world - 1):
+        exs[r].records_recv_buffer().copy_(exs[r + 1].records_send_buffer())
+    res = [e.phase_faces(counts) for e in exs]
+    torch.cuda.synchronize()
+
+    rx, ry, rz = shape
+    allv, allf, allk = [], [], []
+    for e, out in zip(exs, res):
+        lshape = tuple(e.grid.shape)
+        ws = e.backend._ws.cpu().numpy()
+        k = vertex_keys_from_workspace(ws, lshape, out.vertices.shape[0], capi.debug_layout(*lshape),
+                                       halo_last_plane=e.has_halo)
+        lin, ax = k // 3, k % 3
+        allk.append((lin + e.x0 * ry * rz) * 3 + ax)  # local voxel index -> global
+        allv.append(out.vertices.cpu().numpy())
+        allf.append(out.faces.cpu().numpy())
+        assert out.vertex_base == sum(c[0] for c in counts[:e.rank])
+    hip = (np.concatenate(allv), np.concatenate(allf), np.concatenate(allk))
+    _assert_same_mesh(hip, oracle_extract(g, thresh, lower, upper))
+
+
+def test_single_rank_slab_equals_plain_call(gpu):
+    from primitive3d_amd.slab import extract_in_process
+    g = np.random.default_rng(3).standard_normal((9, 8, 70)).astype(np.float32)
+    (out,) = extract_in_process(torch.from_numpy(g).to(gpu), 1, 0.0)
+    rv, rf, _ = oracle_extract(g, 0.0)
+    assert out.vertices.shape == rv.shape and out.faces.shape == rf.shape

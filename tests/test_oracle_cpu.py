@@ -1,0 +1,116 @@
+"""CPU tests of the oracle itself: pinned against the reference's known answers (tests/golden/
+known_answers.json <- SURVEY.md section 4), an independent numpy count, mesh invariants, and the
+committed canonical meshes."""
+import hashlib
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import canonical_mesh, oracle_count, oracle_extract, oracle_tri_table
+from oracle.np_counts import np_count, tri_counts
+from primitive3d_amd.fields import sphere_grid
+from tests.cases import small_cases
+
+GOLD = Path(__file__).resolve().parent / "golden"
+KNOWN = json.loads((GOLD / "known_answers.json").read_text())
+
+
+def _edges(faces):
+    e = np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]])
+    return e
+
+
+def _mesh_stats(v, f):
+    e = _edges(f.astype(np.int64))
+    und = np.sort(e, axis=1)
+    uniq, cnt = np.unique(und, axis=0, return_counts=True)
+    duniq, dcnt = np.unique(e, axis=0, return_counts=True)
+    a, b, c = (v[f[:, i]].astype(np.float64) for i in range(3))
+    vol = float(np.einsum("ij,ij->i", a, np.cross(b, c)).sum() / 6.0)
+    area2 = np.linalg.norm(np.cross(b - a, c - a), axis=1)
+    return {"E": len(uniq), "edge_use_ok": bool((cnt == 2).all()), "dir_edge_once": bool((dcnt == 1).all()),
+            "volume": vol, "zero_area": int((area2 == 0).sum()),
+            "dup_pos": int(len(v) - len(np.unique(v, axis=0)))}
+
+
+def test_case_table_bytes_match_reference_sha():
+    t = oracle_tri_table()
+    assert hashlib.sha256(t.tobytes()).hexdigest() == KNOWN["tri_table_sha256"]
+    assert (t[:, 15] == -1).all()
+    hist = np.bincount(tri_counts(), minlength=6)
+    assert {str(i): int(n) for i, n in enumerate(hist)} == KNOWN["tri_count_histogram"]
+
+
+def test_sphere200_known_answers_and_manifold():
+    k = KNOWN["cases"]["sphere200"]
+    g = sphere_grid(200)  # examples/sphere.py:8-9, int64; the wrapper casts to f32
+    assert oracle_count(g, k["thresh"]) == (k["V"], k["F"])
+    v, f, _ = oracle_extract(g, k["thresh"])
+    st = _mesh_stats(v, f)
+    assert st["E"] == k["E"] and st["edge_use_ok"] and st["dir_edge_once"]
+    assert k["V"] - st["E"] + k["F"] == k["euler"]
+    assert st["zero_area"] == k["zero_area_triangles"] and st["dup_pos"] == k["duplicate_positions"]
+    assert round(st["volume"]) == k["signed_volume"]
+    assert v.min(0).tolist() == k["bbox_min"] and v.max(0).tolist() == k["bbox_max"]
+    assert np_count(g, 0)[2] == k["active_cells"]
+
+
+def test_bunny66_known_answers():
+    k = KNOWN["cases"]["bunny66"]
+    g = np.load(GOLD / "bunny66.npy")
+    assert g.shape == (66, 66, 66) and g.dtype == np.float32
+    assert oracle_count(g, 0) == (k["V"], k["F"])
+    v, f, _ = oracle_extract(g, 0)
+    st = _mesh_stats(v, f)
+    assert st["E"] == k["E"] and st["edge_use_ok"] and st["dir_edge_once"] and k["V"] - st["E"] + k["F"] == 2
+    assert st["zero_area"] == 0 and st["dup_pos"] == 0
+    assert np.allclose(v.min(0), k["vmin"], rtol=0, atol=1e-6) and np.allclose(v.max(0), k["vmax"], rtol=0, atol=1e-5)
+    assert v.min(0).astype(np.float32).tolist() == np.float32(k["vmin"]).tolist()
+    assert np_count(g, 0)[2] == k["active_cells"]
+
+
+def test_sphere64_known_answers():
+    k = KNOWN["cases"]["sphere64"]
+    assert oracle_count(sphere_grid(64), 0) == (k["V"], k["F"])
+
+
+@pytest.mark.parametrize("name", sorted(small_cases().keys()))
+def test_numpy_count_agrees_with_c_oracle(name):
+    g, thresh, _, _ = small_cases()[name]
+    v, f, _ = np_count(g, thresh)
+    assert oracle_count(g, thresh) == (v, f)
+
+
+def test_committed_canonical_meshes_reproduce():
+    z = np.load(GOLD / "small_meshes.npz")
+    for name, (g, thresh, lower, upper) in small_cases().items():
+        k, v, f = canonical_mesh(*oracle_extract(g, thresh, lower, upper))
+        assert np.array_equal(k, z[name + "__keys"]), name
+        assert np.array_equal(f, z[name + "__faces"]), name
+        assert np.array_equal(v, z[name + "__verts"], equal_nan=True), name
+
+
+def test_epilogue_quirk_and_separate_rounding():
+    """marching_cubes.cu:293-298: y scale uses upper[2]-lower[1]; multiply then add, each rounded to fp32."""
+    g, thresh, lower, upper = small_cases()["noise_5x7x9_box"]
+    v, _, keys = oracle_extract(g, thresh, lower, upper)
+    # grid-unit positions: x,y from a call whose x/y scales are exactly 1 (upper[2]=7 feeds the y scale),
+    # z from a call whose z scale is exactly 1
+    ra, _, keys0 = oracle_extract(g, thresh, [0, 0, 0], [5, 0, 7])
+    rb, _, _ = oracle_extract(g, thresh, [0, 0, 0], [5, 0, 9])
+    raw = np.stack([ra[:, 0], ra[:, 1], rb[:, 2]], axis=1)
+    assert np.array_equal(keys, keys0)
+    lo, up = np.float32(lower), np.float32(upper)
+    scale = np.array([(up[0] - lo[0]) / np.float32(5), (up[2] - lo[1]) / np.float32(7), (up[2] - lo[2]) / np.float32(9)],
+                     dtype=np.float32)
+    expect = (raw * scale).astype(np.float32) + lo
+    assert np.array_equal(v, expect.astype(np.float32))
+
+
+def test_strict_greater_and_nan_are_outside():
+    g = np.zeros((2, 2, 2), np.float32)  # every sample == thresh: nothing is inside
+    assert oracle_count(g, 0.0) == (0, 0)
+    g[0, 0, 0] = np.nan
+    assert oracle_count(g, -1.0)[0] == 3  # NaN > t is false: the NaN corner is the only outside sample

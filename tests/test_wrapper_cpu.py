@@ -1,0 +1,118 @@
+"""The Python wrapper (primitive3d_amd/marching_cubes.py) against the behaviour captured from the
+reference wrapper (tests/golden/wrapper_cases.json <- tools/capture_wrapper_cases.py): same lower/
+upper, dtype coercion, contiguity pass-through, exceptions and prints.  No GPU: `_C` is replaced by
+a recorder and CUDA availability is faked, exactly as in the capture."""
+import contextlib
+import io
+import json
+from pathlib import Path
+
+import numpy as np  # noqa: F401  (used by eval of the captured expressions)
+import pytest
+import torch
+
+CASES = json.loads((Path(__file__).resolve().parent / "golden" / "wrapper_cases.json").read_text())
+
+
+@pytest.fixture()
+def wrapper(built, monkeypatch):
+    import importlib
+    w = importlib.import_module("primitive3d_amd.marching_cubes")  # (the package re-exports a function of that name)
+    calls = []
+
+    class Rec:
+        @staticmethod
+        def marching_cubes(grid, thresh, lower, upper):
+            calls.append({"dtype": str(grid.dtype), "shape": list(grid.shape), "contiguous": bool(grid.is_contiguous()),
+                          "thresh": thresh, "thresh_type": type(thresh).__name__,
+                          "lower": [float(v) for v in lower], "upper": [float(v) for v in upper],
+                          "lower_types": [type(v).__name__ for v in lower], "upper_types": [type(v).__name__ for v in upper]})
+            return torch.zeros((0, 3)), torch.zeros((0, 3), dtype=torch.int32)
+
+        @staticmethod
+        def save_mesh_as_ply(fn, v, f, c):
+            calls.append({"save": [str(fn), str(v.dtype), str(f.dtype), str(c.dtype), c.flatten()[:3].tolist()]})
+
+    monkeypatch.setattr(w, "_C", Rec)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    return w, calls
+
+
+@pytest.mark.parametrize("rec", CASES["scale_to_bound"], ids=lambda r: r["name"])
+def test_scale_to_bound(wrapper, rec):
+    w, _ = wrapper
+    if "raises" in rec:
+        with pytest.raises(eval(rec["raises"])):
+            w.scale_to_bound(eval(rec["expr"]))
+    else:
+        lo, up = w.scale_to_bound(eval(rec["expr"]))
+        assert [float(v) for v in lo] == rec["lower"] and [float(v) for v in up] == rec["upper"]
+
+
+@pytest.mark.parametrize("rec", CASES["marching_cubes"], ids=lambda r: r["name"])
+def test_marching_cubes_wrapper(wrapper, rec):
+    w, calls = wrapper
+    kw = dict(rec["kwargs"])
+    if isinstance(kw.get("scale"), list) and len(kw["scale"]) == 2 and isinstance(kw["scale"][0], list):
+        kw["scale"] = (kw["scale"][0], kw["scale"][1])
+    buf = io.StringIO()
+    if "raises" in rec:
+        with pytest.raises(eval(rec["raises"])) as ei, contextlib.redirect_stdout(buf):
+            w.marching_cubes(eval(rec["grid"]), eval(rec["thresh"]), **kw)
+        assert str(ei.value) == rec["message"]
+    else:
+        with contextlib.redirect_stdout(buf):
+            v, f = w.marching_cubes(eval(rec["grid"]), eval(rec["thresh"]), **kw)
+        assert calls[0] == rec["call"]
+    assert buf.getvalue() == rec["stdout"]
+
+
+@pytest.mark.parametrize("rec", CASES["save_mesh"], ids=lambda r: r["name"])
+def test_save_mesh_wrapper(wrapper, rec):
+    from pathlib import Path  # noqa: F811
+    w, calls = wrapper
+    kw = rec["kwargs"]
+    v, f, args = torch.zeros((2, 3)), torch.zeros((1, 3), dtype=torch.int64), {}
+    if kw.get("np"):
+        v, f = v.numpy(), f.numpy()
+        args["colors"] = np.full((2, 3), 200.7)
+    fn = eval(kw["filename"]) if kw["filename"].startswith("Path") else kw["filename"]
+    buf = io.StringIO()
+    if "raises" in rec:
+        with pytest.raises(eval(rec["raises"])):
+            w.save_mesh(v, f, filename=fn, verbose=kw.get("verbose", False), **args)
+    else:
+        with contextlib.redirect_stdout(buf):
+            w.save_mesh(v, f, filename=fn, verbose=kw.get("verbose", False), **args)
+        assert calls[0] == rec["call"]
+    assert buf.getvalue() == rec["stdout"]
+
+
+def test_ply_writer_bytes(built, tmp_path):
+    """save_mesh_as_ply layout (marching_cubes.cu:318-349): header text, xyz f32 + rgb u8 per vertex,
+    [3, i, j, k] int32 per face."""
+    v = torch.tensor([[0.0, 1.0, 2.0], [3.5, -4.0, 5.25]])
+    f = torch.tensor([[0, 1, 1]], dtype=torch.int32)
+    c = torch.tensor([[1, 2, 3], [250, 251, 252]], dtype=torch.uint8)
+    p = tmp_path / "m.ply"
+    built.libPrim3D.save_mesh_as_ply(str(p), v, f, c)
+    data = p.read_bytes()
+    head = (b"ply\nformat binary_little_endian 1.0\nelement vertex 2\nproperty float x\nproperty float y\n"
+            b"property float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nelement face 1\n"
+            b"property list int int vertex_index\nend_header\n")
+    assert data.startswith(head)
+    body = data[len(head):]
+    expect = b"".join(np.float32(v[i].numpy()).tobytes() + bytes(c[i].tolist()) for i in range(2)) \
+        + np.array([3, 0, 1, 1], dtype=np.int32).tobytes()
+    assert body == expect
+
+
+def test_package_surface(built):
+    import prim3d
+    assert prim3d.ENABLE_OPTIX is False and prim3d.__version__
+    assert prim3d.libPrim3D is built.libPrim3D
+    for name in ("marching_cubes", "save_mesh_as_ply", "test", "create_raycaster", "RayCaster", "enable_optix"):
+        assert hasattr(prim3d.libPrim3D, name)
+    with prim3d.Timer("took {:.6f}s"):
+        pass

@@ -5,7 +5,7 @@ checks the records themselves: every id in [0, V) must be assigned exactly once.
 import numpy as np
 
 
-def vertex_keys_from_workspace(ws: np.ndarray, shape, nv: int, layout: dict) -> np.ndarray:
+def vertex_keys_from_workspace(ws: np.ndarray, shape, nv: int, layout: dict, halo_last_plane: bool = False) -> np.ndarray:
     rx, ry, rz = shape
     ncz, U = layout["chunks_per_row"], layout["num_units"]
     assert U == rx * ry * ncz
@@ -22,6 +22,9 @@ def vertex_keys_from_workspace(ws: np.ndarray, shape, nv: int, layout: dict) -> 
     cx[:-1] = (inside[:-1] != inside[1:]) & valid[:-1]
     cy[:, :-1] = (inside[:, :-1] != inside[:, 1:]) & valid[:, :-1]
     cz[:, :, :rz - 1] = inside[:, :, :rz - 1] != inside[:, :, 1:rz]
+    if halo_last_plane:  # in-plane edges of a halo plane belong to the next rank (include/p3d_mc.h: p3d_mc_slab)
+        cy[-1] = False
+        cz[-1] = False
     keys = np.full((nv,), -1, dtype=np.int64)
     lin = (np.arange(rx)[:, None, None] * ry + np.arange(ry)[None, :, None]) * rz + np.arange(zpad)[None, None, :]
     base = rec[..., 0].astype(np.int64)
