@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define P3D_MC_ABI_VERSION 1
+#define P3D_MC_ABI_VERSION 2
 
 /* dtype of the scalar field */
 #define P3D_F32 0
@@ -71,8 +71,11 @@ int p3d_mc_count(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz
                  const p3d_mc_slab* slab, void* ws, void* stream);
 
 /* Blocking read of the totals (replaces the two .item() calls, marching_cubes.cu:251-252).
- * num_faces is triangles, not indices. */
-int p3d_mc_read_counts(const void* ws, int64_t* num_vertices, int64_t* num_faces, void* stream);
+ * num_faces is triangles, not indices.  scratch_overflow (nullable) is set to 1 when the scratch
+ * buffer handed to p3d_mc_extract_fused was too small for some output region (the vertex buffer is
+ * then incomplete and p3d_mc_emit must be used to rewrite it; ids and counts stay valid). */
+int p3d_mc_read_counts(const void* ws, int64_t* num_vertices, int64_t* num_faces, int32_t* scratch_overflow,
+                       void* stream);
 
 /* Phase 2 (replaces gen_vertices_kernel, gen_faces_kernel and the epilogue, marching_cubes.cu:266-298):
  * write vertices [V,3] f32 already mapped to the bounding box (v * scale + lower, scale as in
@@ -88,17 +91,22 @@ int p3d_mc_emit(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz,
 
 /* One-pass variant of count+emit for callers that can guess the output size (steady-state use: the
  * same grid shape every frame).  Reads the field ONCE: classification, vertex ids and vertex
- * emission happen in the same streaming kernel, faces follow from the sign bitfield.  At most
- * cap_vertices / cap_faces rows are written; the true totals are always computed and are read with
- * p3d_mc_read_counts afterwards.  If a total exceeds its capacity the caller allocates exact buffers
- * and calls p3d_mc_emit on the same ws (no re-count needed: ids already assigned stay valid).
- * cap_vertices = cap_faces = 0 makes this a pure count.  With slab->halo_last_plane the face pass
+ * emission happen in the same streaming kernel, faces follow from the sign bitfield.  Vertices are
+ * first written into `vertex_scratch` ([scratch_rows,3] f32, caller-owned, not needed afterwards):
+ * it is cut into 32 regions that fill independently (one output cursor per XCD group and wave, so
+ * no single atomic address serialises the chip), then copied back to back into `vertices`; size it
+ * about 1.25x the expected vertex count.  At most cap_vertices / cap_faces rows are written; the
+ * true totals are always computed and are read with p3d_mc_read_counts afterwards.  If a total
+ * exceeds its capacity, or a scratch region overflowed, the caller allocates exact buffers and calls
+ * p3d_mc_emit on the same ws (no re-count needed: ids already assigned stay valid).
+ * cap_vertices = cap_faces = 0 (scratch may be NULL) makes this a pure count.  With slab->halo_last_plane the face pass
  * is skipped (the caller imports the halo records first, then calls p3d_mc_emit with cap_vertices=0).
  * Replaces the same reference code as p3d_mc_count + p3d_mc_emit (marching_cubes.cu:229-298). */
 int p3d_mc_extract_fused(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz, float thresh,
                          const float lower[3], const float upper[3], const int64_t full_res[3],
                          const p3d_mc_slab* slab, void* ws, float* vertices, int64_t cap_vertices,
-                         int32_t* faces, int64_t cap_faces, void* stream);
+                         float* vertex_scratch, int64_t scratch_rows, int32_t* faces, int64_t cap_faces,
+                         void* stream);
 
 /* Test hook: where the sign bitfield (u64 per 64-voxel unit, unit u = (x*ry+y)*ncz + c) and the
  * vertex-id records ({u32 base, u32 offY | offZ<<16} per unit) live inside `ws`, so a test can
@@ -117,7 +125,7 @@ int p3d_mc_plane_records(void* ws, int64_t rx, int64_t ry, int64_t rz, int64_t p
  * Timer of prim3d/misc/utils.py:41-116).  mode 0 = off, 1 = hipEvents around the dominant kernel
  * only, 2 = around every stage.  Events are recorded on the stream passed to count/emit.
  * p3d_mc_profile_read synchronises those events and returns the per-stage durations (ms, -1 = not
- * recorded) of the most recent count/emit pair; it returns the number of stages (9; pass n >= 9). */
+ * recorded) of the most recent count/emit pair; it returns the number of stages (10; pass n >= 10). */
 int p3d_mc_profile_enable(int mode);
 int p3d_mc_profile_read(float* stage_ms, int n);
 const char* p3d_mc_profile_stage_name(int stage);

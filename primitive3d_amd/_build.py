@@ -40,7 +40,7 @@ def build_capi(force: bool = False, verbose: bool = False) -> Path:
     if force or _stale(out, deps):
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
                # the reference epilogue is mul-then-add, never an FMA (marching_cubes.cu:298)
-               "-ffp-contract=off", "-Wall", "-Wextra", "-DP3D_FUSED_CAP=1024", "-DP3D_FUSED_WAVES_PER_EU=4",
+               "-ffp-contract=off", "-Wall", "-Wextra", 
                str(CSRC / "p3d_mc.hip"), "-o", str(out)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

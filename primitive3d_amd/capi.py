@@ -41,7 +41,7 @@ def lib():
         L.p3d_last_error.restype = c_char_p
         L.p3d_mc_workspace_bytes.argtypes = [c_int64, c_int64, c_int64, POINTER(c_size_t)]
         L.p3d_mc_count.argtypes = [c_void_p, c_int, c_int64, c_int64, c_int64, c_float, POINTER(Slab), c_void_p, c_void_p]
-        L.p3d_mc_read_counts.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_int64), c_void_p]
+        L.p3d_mc_read_counts.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32), c_void_p]
         L.p3d_mc_emit.argtypes = [c_void_p, c_int, c_int64, c_int64, c_int64, c_float, POINTER(c_float * 3),
                                   POINTER(c_float * 3), POINTER(c_int64 * 3), POINTER(Slab), c_void_p, c_void_p,
                                   c_int64, c_void_p, c_int64, c_void_p, c_void_p]
@@ -49,7 +49,7 @@ def lib():
                                            POINTER(c_size_t)]
         L.p3d_mc_extract_fused.argtypes = [c_void_p, c_int, c_int64, c_int64, c_int64, c_float, POINTER(c_float * 3),
                                            POINTER(c_float * 3), POINTER(c_int64 * 3), POINTER(Slab), c_void_p,
-                                           c_void_p, c_int64, c_void_p, c_int64, c_void_p]
+                                           c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]
         L.p3d_mc_debug_layout.argtypes = [c_int64, c_int64, c_int64, POINTER(c_size_t), POINTER(c_size_t),
                                           POINTER(c_int64), POINTER(c_int32)]
         L.p3d_mc_profile_enable.argtypes = [c_int]
@@ -98,11 +98,11 @@ def count(grid, thresh, ws, slab=None):
                               _stream_ptr(grid)), "p3d_mc_count")
 
 
-def read_counts(ws):
-    v, f = c_int64(0), c_int64(0)
-    _check(lib().p3d_mc_read_counts(c_void_p(ws.data_ptr()), byref(v), byref(f), _stream_ptr(ws)),
+def read_counts(ws, with_flags=False):
+    v, f, o = c_int64(0), c_int64(0), c_int32(0)
+    _check(lib().p3d_mc_read_counts(c_void_p(ws.data_ptr()), byref(v), byref(f), byref(o), _stream_ptr(ws)),
            "p3d_mc_read_counts")
-    return v.value, f.value
+    return (v.value, f.value, bool(o.value)) if with_flags else (v.value, f.value)
 
 
 def emit(grid, thresh, lower, upper, ws, vertices, faces, vertex_keys=None, slab=None, full_res=None):
@@ -134,8 +134,18 @@ def profile_read():
     return {lib().p3d_mc_profile_stage_name(i).decode(): buf[i] for i in range(n) if buf[i] >= 0}
 
 
-def extract_fused_raw(grid, thresh, lower, upper, ws, vertices, faces, slab=None, full_res=None):
-    """p3d_mc_extract_fused: one pass over the field, writes at most the capacities of the two buffers."""
+def scratch_rows_for(cap_vertices: int) -> int:
+    """Rows of vertex scratch for an expected vertex count: 32 regions, 25 % + 256 rows of slack each."""
+    per = (cap_vertices + 31) // 32
+    return 32 * (per + per // 4 + 256)
+
+
+def extract_fused_raw(grid, thresh, lower, upper, ws, vertices, faces, slab=None, full_res=None, scratch=None):
+    """p3d_mc_extract_fused: one pass over the field, writes at most the capacities of the two buffers.
+    `scratch` ([rows,3] f32) is required when `vertices` is given; allocated here if omitted."""
+    import torch
+    if vertices is not None and vertices.shape[0] and scratch is None:
+        scratch = torch.empty((scratch_rows_for(vertices.shape[0]), 3), dtype=torch.float32, device=grid.device)
     rx, ry, rz = grid.shape
     lo = (c_float * 3)(*[float(v) for v in lower])
     up = (c_float * 3)(*[float(v) for v in upper])
@@ -146,6 +156,7 @@ def extract_fused_raw(grid, thresh, lower, upper, ws, vertices, faces, slab=None
                                       byref(lo), byref(up), byref(fr) if fr is not None else None,
                                       byref(slab) if slab is not None else None, c_void_p(ws.data_ptr()),
                                       c_void_p(vertices.data_ptr()) if capv else None, capv,
+                                      c_void_p(scratch.data_ptr()) if capv else None, scratch.shape[0] if capv else 0,
                                       c_void_p(faces.data_ptr()) if capf else None, capf, _stream_ptr(grid)),
            "p3d_mc_extract_fused")
 
@@ -169,8 +180,8 @@ def extract_fused(grid, thresh, lower=None, upper=None, cap_vertices=None, cap_f
     verts = torch.empty((capv, 3), dtype=torch.float32, device=grid.device)
     faces = torch.empty((capf, 3), dtype=torch.int32, device=grid.device)
     extract_fused_raw(grid, thresh, lower, upper, ws, verts, faces)
-    nv, nf = read_counts(ws)
-    if nv > capv or nf > capf:
+    nv, nf, over = read_counts(ws, with_flags=True)
+    if nv > capv or nf > capf or over:
         verts = torch.empty((nv, 3), dtype=torch.float32, device=grid.device)
         faces = torch.empty((nf, 3), dtype=torch.int32, device=grid.device)
         emit(grid, thresh, lower, upper, ws, verts, faces)

@@ -70,7 +70,7 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     if (exact_mode) {
         // two-phase: count (reads the field), host sync, exact allocation, emit (reads the active part again)
         check_rc(p3d_mc_count(grid, P3D_F32, rx, ry, rz, thresh, nullptr, ws.data_ptr(), stream), "p3d_mc_count");
-        check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, stream), "p3d_mc_read_counts");
+        check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, nullptr, stream), "p3d_mc_read_counts");
         vertices = torch::empty({nv, 3}, vopt);
         faces = torch::empty({nf, 3}, fopt);
         check_rc(p3d_mc_emit(grid, P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, nullptr,
@@ -98,16 +98,21 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     }
     vertices = torch::empty({capv, 3}, vopt);
     faces = torch::empty({capf, 3}, fopt);
+    // vertex scratch: 32 independently filled regions (25 % + 256 rows of slack each); freed on return
+    const int64_t per_region = (capv + 31) / 32;
+    const int64_t scratch_rows = 32 * (per_region + per_region / 4 + 256);
+    Tensor scratch = torch::empty({scratch_rows, 3}, vopt);
     check_rc(p3d_mc_extract_fused(grid, P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, nullptr,
-                                  ws.data_ptr(), vertices.data_ptr<float>(), capv, faces.data_ptr<int32_t>(), capf,
-                                  stream),
+                                  ws.data_ptr(), vertices.data_ptr<float>(), capv, scratch.data_ptr<float>(),
+                                  scratch_rows, faces.data_ptr<int32_t>(), capf, stream),
              "p3d_mc_extract_fused");
-    check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, stream), "p3d_mc_read_counts");
+    int32_t overflow = 0;
+    check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, &overflow, stream), "p3d_mc_read_counts");
     {
         std::lock_guard<std::mutex> g(g_cap_mu);
         g_cap_hint[key] = {nv, nf};
     }
-    if (nv > capv || nf > capf) {
+    if (nv > capv || nf > capf || overflow) {
         vertices = torch::empty({nv, 3}, vopt);
         faces = torch::empty({nf, 3}, fopt);
         check_rc(p3d_mc_emit(grid, P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, nullptr,

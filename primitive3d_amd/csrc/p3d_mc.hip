@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "../../include/p3d_mc.h"
@@ -54,9 +55,9 @@ struct Ws {  // byte offsets into the workspace
 };
 
 constexpr int kBlock = 256;
-constexpr int kHdrBytes = 256;
+constexpr int kHdrBytes = 8192;   // [0,256) totals/flags; [256,4352) 32 cursors, one 128-B line each; [4352,4608) region prefixes
 // header slots (u64)
-enum { H_V = 0, H_T = 1 };
+enum { H_V = 0, H_T = 1, H_FLAGS = 2, H_CURSORS = 32 /* u64 index */, H_PREFIX = 32 + 32 * 16 };
 
 __host__ __device__ inline Dims make_dims(int64_t rx, int64_t ry, int64_t rz) {
     Dims d;
@@ -571,10 +572,10 @@ int grid_for(int64_t work_items, int per_block, int64_t cap) {
 
 // ---- optional stage timing (bench/roofline): hipEvents recorded on the caller's stream ----------
 enum { ST_CLASSIFY = 0, ST_UNIT_COUNTS, ST_SCAN_V, ST_UNIT_RECORDS, ST_FACES_COUNT, ST_SCAN_F, ST_EMIT_VERTS,
-       ST_EMIT_FACES, ST_FUSED, ST_N };
+       ST_EMIT_FACES, ST_FUSED, ST_FINALIZE, ST_N };
 const char* const k_stage_names[ST_N] = {"k_classify",    "k_unit_counts", "k_scan_blocks(v)", "k_unit_records",
                                          "k_faces<count>", "k_scan_blocks(f)", "k_emit_vertices", "k_faces<emit>",
-                                         "k_fused"};
+                                         "k_fused", "k_finalize(prefix+fix_records+compact)"};
 int g_prof_mode = 0;  // 0 off, 1 dominant kernel only (k_classify), 2 every stage
 hipEvent_t g_ev[ST_N][2];
 bool g_ev_made = false;
@@ -676,7 +677,7 @@ int env_int(const char* name, int dflt) {
 
 template <typename T, int NC, int RY>
 void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xform& t, int64_t x_origin, u64* bits,
-                  uint2* rec, u64* cursor, float* verts, int64_t capv, hipStream_t st) {
+                  uint2* rec, u64* cursors, float* scratch, u32 region_rows, u32 store_rows, hipStream_t st) {
     FusedGeom g;
     g.nzt = (d.ncz + NC - 1) / NC;
     g.nyt = (int)((d.ry + kFusedWPB * RY - 1) / (kFusedWPB * RY));
@@ -689,16 +690,18 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
     g.XT = xt;
     g.nxt = (int)((d.rx + xt - 1) / xt);
     const int64_t nblocks = per_slab * g.nxt;
-    hipLaunchKernelGGL((k_fused<T, NC, RY, P3D_FUSED_CAP>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, grid, thresh, d, g,
-                       halo, t, x_origin, bits, rec, cursor, verts, capv);
+    hipLaunchKernelGGL((k_fused<T, NC, RY>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, grid, thresh, d, g, halo, t,
+                       x_origin, bits, rec, cursors, scratch, region_rows, store_rows);
 }
 
 template <typename T>
 void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xform& t, int64_t x_origin, u64* bits,
-                    uint2* rec, u64* cursor, float* verts, int64_t capv, hipStream_t st) {
+                    uint2* rec, u64* cursors, float* scratch, u32 region_rows, u32 store_rows, hipStream_t st) {
     // two tile geometries (both hold 32 unit words per wave-plane): long rows / short rows
-    if (d.ncz >= 3) launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursor, verts, capv, st);
-    else launch_fused<T, 2, 15>(grid, d, thresh, halo, t, x_origin, bits, rec, cursor, verts, capv, st);
+    if (d.ncz >= 3)
+        launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, scratch, region_rows, store_rows, st);
+    else
+        launch_fused<T, 2, 15>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, scratch, region_rows, store_rows, st);
 }
 
 Xform make_xform(const Dims& d, const float lower[3], const float upper[3], const int64_t full_res[3]) {
@@ -716,17 +719,33 @@ Xform make_xform(const Dims& d, const float lower[3], const float upper[3], cons
 
 template <typename T>
 int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xform& t, const p3d_mc_slab* slab,
-               char* ws, float* verts, int64_t capv, int32_t* faces, int64_t capf, hipStream_t st) {
+               char* ws, float* verts, int64_t capv, float* scratch, int64_t scratch_rows, int32_t* faces,
+               int64_t capf, hipStream_t st) {
     const int halo = slab ? slab->halo_last_plane : 0;
     u64* hdr = (u64*)(ws + w.hdr);
     u64* bits = (u64*)(ws + w.bits);
     uint2* rec = (uint2*)(ws + w.rec);
     u32 *bsf = (u32*)(ws + w.bsum_f), *bbf = (u32*)(ws + w.bbase_f);
+    u64 *cursors = hdr + H_CURSORS, *prefix = hdr + H_PREFIX;
+    // Vertex ids handed out by the streaming kernel are region * 2^26 + slot (a fixed stride, so they stay
+    // unambiguous even when a region outgrows its share of the scratch buffer); k_fix_records makes them dense.
+    // Storage is store_rows rows per region; without a scratch buffer nothing is stored (pure count + ids).
+    const u32 region_rows = 1u << 26;
+    const u32 store_rows = scratch ? (u32)std::min<int64_t>(scratch_rows / kRegions, (int64_t)region_rows) : 0u;
     HIP_TRY(hipMemsetAsync(hdr, 0, kHdrBytes, st));
     {
         StageTimer tm(ST_FUSED, st);
         const int64_t xo = slab ? slab->x_origin : 0;
-        dispatch_fused<T>(grid, d, thresh, halo, t, xo, bits, rec, hdr + H_V, verts, capv, st);
+        dispatch_fused<T>(grid, d, thresh, halo, t, xo, bits, rec, cursors, scratch, region_rows, store_rows, st);
+    }
+    {
+        StageTimer tm(ST_FINALIZE, st);
+        hipLaunchKernelGGL(k_region_prefix, dim3(1), dim3(64), 0, st, hdr, cursors, prefix,
+                           scratch ? store_rows : region_rows);
+        hipLaunchKernelGGL(k_fix_records, dim3((u32)w.nb_v), dim3(256), 0, st, rec, d.U, prefix, region_rows);
+        if (scratch && capv > 0)
+            hipLaunchKernelGGL(k_compact, dim3(64, kRegions), dim3(256), 0, st, scratch, cursors, prefix, store_rows,
+                               verts, capv);
     }
     FaceArgs a{halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0, w.tpp};
     if (w.nb_f > 0) {
@@ -776,15 +795,17 @@ int p3d_mc_count(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz
     return fail(P3D_EINVAL, "unknown dtype%s");
 }
 
-int p3d_mc_read_counts(const void* ws, int64_t* num_vertices, int64_t* num_faces, void* stream) {
+int p3d_mc_read_counts(const void* ws, int64_t* num_vertices, int64_t* num_faces, int32_t* scratch_overflow,
+                       void* stream) {
     if (!ws || !num_vertices || !num_faces) return fail(P3D_EINVAL, "null pointer%s");
-    u64 h[2] = {0, 0};
+    u64 h[3] = {0, 0, 0};
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(h, ws, sizeof(h), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     *num_vertices = (int64_t)h[H_V];
     *num_faces = (int64_t)h[H_T];
-    if (h[H_V] > 0x7fffffffull || h[H_T] * 3 > 0x7fffffffull * 3)
+    if (scratch_overflow) *scratch_overflow = (int32_t)(h[H_FLAGS] & 1ull);
+    if (h[H_V] > 0x7fffffffull || h[H_T] > 0x7fffffffull)
         return fail(P3D_ERANGE, "vertex/face count exceeds int32 indexing%s");
     return P3D_OK;
 }
@@ -810,22 +831,25 @@ int p3d_mc_emit(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz,
 
 int p3d_mc_extract_fused(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz, float thresh,
                          const float lower[3], const float upper[3], const int64_t full_res[3],
-                         const p3d_mc_slab* slab, void* ws, float* vertices, int64_t cap_vertices, int32_t* faces,
-                         int64_t cap_faces, void* stream) {
+                         const p3d_mc_slab* slab, void* ws, float* vertices, int64_t cap_vertices,
+                         float* vertex_scratch, int64_t scratch_rows, int32_t* faces, int64_t cap_faces,
+                         void* stream) {
     if (!grid || !ws || !lower || !upper) return fail(P3D_EINVAL, "null pointer%s");
     if ((cap_vertices > 0 && !vertices) || (cap_faces > 0 && !faces)) return fail(P3D_EINVAL, "null output%s");
-    if (cap_vertices < 0 || cap_faces < 0) return fail(P3D_EINVAL, "negative capacity%s");
+    if (cap_vertices < 0 || cap_faces < 0 || scratch_rows < 0) return fail(P3D_EINVAL, "negative capacity%s");
+    if (cap_vertices > 0 && (!vertex_scratch || scratch_rows < kRegions))
+        return fail(P3D_EINVAL, "vertex output needs a scratch buffer of at least 32 rows%s");
     if (int rc = check_dims(rx, ry, rz)) return rc;
     const Dims d = make_dims(rx, ry, rz);
     const Ws w = make_ws(d);
     const Xform t = make_xform(d, lower, upper, full_res);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == P3D_F32)
-        return fused_impl((const float*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices, faces,
-                          cap_faces, st);
+        return fused_impl((const float*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices, vertex_scratch,
+                          scratch_rows, faces, cap_faces, st);
     if (dtype == P3D_F16)
-        return fused_impl((const __half*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices, faces,
-                          cap_faces, st);
+        return fused_impl((const __half*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices,
+                          vertex_scratch, scratch_rows, faces, cap_faces, st);
     return fail(P3D_EINVAL, "unknown dtype%s");
 }
 
@@ -855,7 +879,7 @@ int p3d_mc_profile_enable(int mode) {
 }
 
 int p3d_mc_profile_read(float* stage_ms, int n) {
-    if (!stage_ms || n < ST_N) return fail(P3D_EINVAL, "need room for 9 stages%s");
+    if (!stage_ms || n < ST_N) return fail(P3D_EINVAL, "need room for 10 stages%s");
     for (int i = 0; i < ST_N; ++i) {
         stage_ms[i] = -1.f;
         if (g_ev_made && g_ev_used[i]) {

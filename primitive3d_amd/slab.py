@@ -59,8 +59,8 @@ class HipBackend:
         self._slab = c.Slab(1 if halo else 0, 0, 0, 0, x_origin)
         verts = torch.empty((capv, 3), dtype=torch.float32, device=self.device)
         c.extract_fused_raw(grid, thresh, lower, upper, ws, verts, None, slab=self._slab, full_res=full_res)
-        nv, nf = c.read_counts(ws)
-        if nv > capv:  # guess too small: ids stay valid, redo only the vertex emission into an exact buffer
+        nv, nf, over = c.read_counts(ws, with_flags=True)
+        if nv > capv or over:  # guess too small: ids stay valid, redo only the vertex emission into an exact buffer
             verts = torch.empty((nv, 3), dtype=torch.float32, device=self.device)
             c.emit(grid, thresh, lower, upper, ws, verts, None, slab=self._slab, full_res=full_res)
         self._cap = nv + nv // 8 + 4096
