@@ -698,6 +698,11 @@ template <typename T>
 void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xform& t, int64_t x_origin, u64* bits,
                     uint2* rec, u64* cursors, float* scratch, u32 region_rows, u32 store_rows, hipStream_t st) {
     // two tile geometries (both hold 32 unit words per wave-plane): long rows / short rows
+#ifdef P3D_EXP_GEOM47
+    if (d.ncz >= 3)
+        launch_fused<T, 4, 7>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, scratch, region_rows, store_rows, st);
+    else
+#endif
     if (d.ncz >= 3)
         launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, scratch, region_rows, store_rows, st);
     else

@@ -2,7 +2,7 @@
 # usage: tools/dev/pmc.sh "<counters>" <outname> -- python3 script...   (one --pmc pass)
 ctr="$1"; out="$2"; shift 2
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$out -- "$@" > $GRAFT_REPO_ROOT/gpurun_out/$out.log 2>&1
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/$out; rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$out -- "$@" > $GRAFT_REPO_ROOT/gpurun_out/$out.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 fs = glob.glob("$GRAFT_REPO_ROOT/gpurun_out/$out/**/*counter_collection.csv", recursive=True)
