@@ -365,69 +365,27 @@ struct FaceArgs {
     int64_t tpp;  // tiles per plane
 };
 
-// owner column (0:(x,y) 1:(x+1,y) 2:(x+1,y+1) 3:(x,y+1)), dz, axis for the 12 cell edges
-__device__ inline void edge_owner(int e, int& col, int& dz, int& axis) {
-    // packed as col | dz<<2 | axis<<3, 5 bits per edge
-    const u64 tab = (u64)(0 | 0 << 2 | 0 << 3) << 0 |    // e0  (x,y,z)     axis0
-                    (u64)(1 | 0 << 2 | 1 << 3) << 5 |    // e1  (x+1,y,z)   axis1
-                    (u64)(3 | 0 << 2 | 0 << 3) << 10 |   // e2  (x,y+1,z)   axis0
-                    (u64)(0 | 0 << 2 | 1 << 3) << 15 |   // e3  (x,y,z)     axis1
-                    (u64)(0 | 1 << 2 | 0 << 3) << 20 |   // e4  (x,y,z+1)   axis0
-                    (u64)(1 | 1 << 2 | 1 << 3) << 25 |   // e5  (x+1,y,z+1) axis1
-                    (u64)(3 | 1 << 2 | 0 << 3) << 30 |   // e6  (x,y+1,z+1) axis0
-                    (u64)(0 | 1 << 2 | 1 << 3) << 35 |   // e7  (x,y,z+1)   axis1
-                    (u64)(0 | 0 << 2 | 2 << 3) << 40 |   // e8  (x,y,z)     axis2
-                    (u64)(1 | 0 << 2 | 2 << 3) << 45 |   // e9  (x+1,y,z)   axis2
-                    (u64)(2 | 0 << 2 | 2 << 3) << 50 |   // e10 (x+1,y+1,z) axis2
-                    (u64)(3 | 0 << 2 | 2 << 3) << 55;    // e11 (x,y+1,z)   axis2
-    const int v = (int)((tab >> (5 * e)) & 31);
-    col = v & 3;
-    dz = (v >> 2) & 1;
-    axis = v >> 3;
-}
+constexpr int kCellCap = 2048;  // active cells expanded at a time (a 256-unit tile has up to 16384)
 
-// vertex id of cell edge e (Bourke numbering, marching_cubes.cu:178-192) for the cell at (unit tu of the
-// tile, bit z): owner unit + rank of the edge among that unit's crossings of the same axis.
-// s_r[t][col] caches rec of the 4 owner columns at the cell's own chunk; the next chunk's record (edge at
-// bit 64 = bit 0 of unit+1) is the neighbouring tile entry when that is the same row, else a global load.
-__device__ inline int64_t edge_vertex_id(int e, const u64 (*s_w)[8], const uint2 (*s_r)[4], int tu, int z, int c,
-                                         int ncz, const int64_t* ucol, const uint2* __restrict__ rec, bool xhalo,
-                                         const FaceArgs& a) {
-    int col, dz, axis;
-    edge_owner(e, col, dz, axis);
-    const int zz = z + dz;
-    u32 rank;
-    uint2 r;
-    if (zz == 64) {  // first voxel of the next chunk: nothing below it
-        rank = 0;
-        r = (tu + 1 < kBlock && c + 1 < ncz) ? s_r[tu + 1][col] : rec[ucol[col] + 1];
-    } else {
-        const u64 W = s_w[tu][col];
-        u64 C;
-        if (axis == 2) C = W ^ s_w[tu][4 + col];
-        else if (axis == 0) C = W ^ s_w[tu][col == 0 ? 1 : 2];  // col 0 -> (x+1,y) ; col 3 -> (x+1,y+1)
-        else C = W ^ s_w[tu][col == 0 ? 3 : 2];                 // col 0 -> (x,y+1) ; col 1 -> (x+1,y+1)
-        rank = (u32)popc64(C & below(zz));
-        r = s_r[tu][col];
-    }
-    const u32 offa = axis == 0 ? 0u : (axis == 1 ? (r.y & 0xffffu) : (r.y >> 16));
-    const bool in_halo = xhalo && (col == 1 || col == 2);
-    return (int64_t)r.x + offa + rank + (in_halo ? a.halo_vid_base : a.vid_base);
-}
-
-constexpr int kCellCap = 4096;  // active cells expanded at a time (a 256-unit tile has up to 16384)
-
+// Faces from sign words + vertex-id records.  One block = 256 units of one x plane.
+//   phase A (lane = unit)        : the 2x2 column words, their next-chunk bits, vertex-id records, active-cell word
+//   phase B (lane = unit)        : dense list of the tile's active cells (8 z-octant rounds if it does not fit)
+//   phase C (lane = active cell) : corner mask, triangle count; EMIT: the cell's 12 edge vertex ids -> LDS
+//   phase D (lane = TRIANGLE)    : three LDS lookups, 12 contiguous bytes stored per lane (fully coalesced)
+// Corner bit weights and edge numbering follow marching_cubes.cu:49-57 and :178-192.
 template <bool EMIT>
 __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, const uint2* __restrict__ rec, Dims d,
                                                   FaceArgs a, const u32* __restrict__ bbase, u32* __restrict__ bsum,
                                                   int32_t* __restrict__ faces, int64_t cap_faces) {
     __shared__ u64 s_tab[256];
     __shared__ unsigned char s_ntri[256];
-    __shared__ u64 s_w[kBlock][8];  // W00,W10,W11,W01 then their z+1 shifts: bit k of word j = corner j of cell k
-    __shared__ uint2 s_r[EMIT ? kBlock : 1][4];      // EMIT: vertex-id records of the 4 owner columns
-    __shared__ unsigned short s_cells[kCellCap];     // active cells of the current round: unit-in-tile << 6 | z
-    __shared__ unsigned char s_cmask[kBlock];        // EMIT: corner mask of the batch's cells
-    __shared__ unsigned short s_tri[kBlock * 5];     // EMIT: triangle -> cell-in-batch << 3 | slot
+    __shared__ u64 s_w[kBlock][4];                    // W00,W10,W11,W01: bit k = sign of corner column j at z = 64c+k
+    __shared__ unsigned char s_nb[kBlock];            // bit j = sign of column j at the first voxel of the next chunk
+    __shared__ uint2 s_r[EMIT ? kBlock : 1][4];       // EMIT: vertex-id records of the 4 owner columns
+    __shared__ unsigned short s_cells[kCellCap];      // active cells of the current round: unit-in-tile << 6 | z
+    __shared__ unsigned char s_cmask[EMIT ? kBlock : 1];       // EMIT: corner mask of the batch's cells
+    __shared__ u32 s_ids[EMIT ? kBlock : 1][12];      // EMIT: vertex ids of the batch's cells' 12 edges
+    __shared__ unsigned short s_tri[EMIT ? kBlock * 5 : 1];    // EMIT: triangle -> cell-in-batch << 3 | slot
     __shared__ u32 s_tmp[4];
 
     const int tid = threadIdx.x;
@@ -443,45 +401,52 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     const int64_t u = x * d.P + p;
     const bool valid = (p < d.P) && (y + 1 < d.ry);  // x+1 < rx by grid construction
 
-    // phase A (lane = unit): 2x2 column words, their z+1 shifts, active-cell word
+    // phase A
     u64 act_all = 0;
     if (valid) {
         const int64_t uc[4] = {u, u + d.P, u + d.P + d.ncz, u + d.ncz};
         u64 orr = 0, andd = ~0ull;
         const bool more = c + 1 < d.ncz;
+        int nbits = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const u64 W = bits[uc[k]];
             const u64 nb = more ? (bits[uc[k] + 1] & 1ull) : 0ull;
             const u64 S = (W >> 1) | (nb << 63);
             s_w[tid][k] = W;
-            s_w[tid][4 + k] = S;
+            nbits |= (int)nb << k;
             if (EMIT) s_r[tid][k] = rec[uc[k]];  // only entries of units that own vertices are meaningful
             orr |= W | S;
             andd &= W & S;
         }
+        s_nb[tid] = (unsigned char)nbits;
         act_all = orr & ~andd & zedge(d, c);
     }
 
-    auto cell_mask = [&](int cell) {
-        const int t = cell >> 6, z = cell & 63;
-        int mask = 0;
+    // corner mask of a cell: bits 0-3 = columns at z, bits 4-7 = the same columns at z+1
+    auto cell_mask = [&](int t, int z) {
+        int lo = 0, hi = 0;
+        const int nbm = s_nb[t];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) mask |= (int)((s_w[t][k] >> z) & 1ull) << k;
-        return mask;
+        for (int k = 0; k < 4; ++k) {
+            const u64 W = s_w[t][k];
+            lo |= (int)((W >> z) & 1ull) << k;
+            hi |= (z < 63 ? (int)((W >> (z + 1)) & 1ull) : ((nbm >> k) & 1)) << k;
+        }
+        return lo | (hi << 4);
     };
 
-    // the tile's cells are expanded into LDS in one round when they fit, else in four z-quarter rounds
+    // the tile's cells are expanded into LDS in one round when they fit, else in eight z-octant rounds
     u32 na_tile;
     (void)block_excl_scan((u32)popc64(act_all), s_tmp, &na_tile);
-    const int rounds = na_tile <= (u32)kCellCap ? 1 : 4;
+    const int rounds = na_tile <= (u32)kCellCap ? 1 : 8;
     const bool xhalo = a.halo_last && (x + 1 == d.rx - 1);  // columns 1,2 live in the imported plane
     u32 run = EMIT ? bbase[b] : 0u;
     u32 my_tris = 0;
 
     for (int rd = 0; rd < rounds; ++rd) {
-        u64 act = rounds == 1 ? act_all : (act_all & (0xffffull << (16 * rd)));
-        // phase B: dense list of active cells
+        u64 act = rounds == 1 ? act_all : (act_all & (0xffull << (8 * rd)));
+        // phase B
         u32 na_total;
         u32 off = block_excl_scan((u32)popc64(act), s_tmp, &na_total);
         while (act) {
@@ -491,41 +456,83 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
         }
         __syncthreads();
 
-        if (!EMIT) {  // phase C (lane = active cell): triangle count
-            for (u32 i = tid; i < na_total; i += kBlock) my_tris += s_ntri[cell_mask(s_cells[i])];
+        if (!EMIT) {  // phase C, count only
+            for (u32 i = tid; i < na_total; i += kBlock) {
+                const int cell = s_cells[i];
+                my_tris += s_ntri[cell_mask(cell >> 6, cell & 63)];
+            }
             continue;  // (next round's scan barriers order the reuse of s_cells)
         }
 
-        // EMIT: batches of 256 cells; lane = cell assigns triangle slots, then lane = TRIANGLE writes 3 indices
-        // (12 contiguous bytes per lane, consecutive lanes contiguous: fully coalesced output)
         for (u32 i0 = 0; i0 < na_total; i0 += kBlock) {
+            // phase C (lane = cell)
             const u32 i = i0 + tid;
             int mask = 0;
-            if (i < na_total) mask = cell_mask(s_cells[i]);
+            if (i < na_total) {
+                const int cell = s_cells[i];
+                const int t = cell >> 6, z = cell & 63;
+                mask = cell_mask(t, z);
+                if (s_ntri[mask]) {
+                    // crossing words of the 4 columns within this chunk
+                    const u64 W0 = s_w[t][0], W1 = s_w[t][1], W2 = s_w[t][2], W3 = s_w[t][3];
+                    const int nbm = s_nb[t];
+                    const u64 lowm = below(z);
+                    const u64 Cx0 = W0 ^ W1, Cx3 = W3 ^ W2;   // axis-0 edges of columns (x,y) and (x,y+1)
+                    const u64 Cy0 = W0 ^ W3, Cy1 = W1 ^ W2;   // axis-1 edges of columns (x,y) and (x+1,y)
+                    const uint2 r0 = s_r[t][0], r1 = s_r[t][1], r2 = s_r[t][2], r3 = s_r[t][3];
+                    const u32 b0 = a.vid_base, bh = xhalo ? (u32)a.halo_vid_base : (u32)a.vid_base;
+                    u32 id[12];
+                    // edges at z (ranks among the bits below z)
+                    id[0] = r0.x + b0 + (u32)popc64(Cx0 & lowm);
+                    id[2] = r3.x + b0 + (u32)popc64(Cx3 & lowm);
+                    id[3] = r0.x + b0 + (r0.y & 0xffffu) + (u32)popc64(Cy0 & lowm);
+                    id[1] = r1.x + bh + (r1.y & 0xffffu) + (u32)popc64(Cy1 & lowm);
+                    // edges at z+1: one more if the edge at z exists; the first voxel of the next chunk has rank 0
+                    if (z < 63) {
+                        id[4] = id[0] + (u32)((Cx0 >> z) & 1ull);
+                        id[6] = id[2] + (u32)((Cx3 >> z) & 1ull);
+                        id[7] = id[3] + (u32)((Cy0 >> z) & 1ull);
+                        id[5] = id[1] + (u32)((Cy1 >> z) & 1ull);
+                    } else {
+                        const int64_t pt = tile * kBlock + t;
+                        const bool in_tile = (t + 1 < kBlock);   // same row: c+1 < ncz is implied by a valid z+1
+                        const int64_t pu = x * d.P + pt;
+                        const uint2 n0 = in_tile ? s_r[t + 1][0] : rec[pu + 1];
+                        const uint2 n1 = in_tile ? s_r[t + 1][1] : rec[pu + d.P + 1];
+                        const uint2 n3 = in_tile ? s_r[t + 1][3] : rec[pu + d.ncz + 1];
+                        id[4] = n0.x + b0;
+                        id[6] = n3.x + b0;
+                        id[7] = n0.x + b0 + (n0.y & 0xffffu);
+                        id[5] = n1.x + bh + (n1.y & 0xffffu);
+                    }
+                    // axis-2 edges of the 4 columns (always inside this chunk)
+                    const u64 S0 = (W0 >> 1) | ((u64)(nbm & 1) << 63), S1 = (W1 >> 1) | ((u64)((nbm >> 1) & 1) << 63);
+                    const u64 S2 = (W2 >> 1) | ((u64)((nbm >> 2) & 1) << 63), S3 = (W3 >> 1) | ((u64)((nbm >> 3) & 1) << 63);
+                    id[8] = r0.x + b0 + (r0.y >> 16) + (u32)popc64((W0 ^ S0) & lowm);
+                    id[9] = r1.x + bh + (r1.y >> 16) + (u32)popc64((W1 ^ S1) & lowm);
+                    id[10] = r2.x + bh + (r2.y >> 16) + (u32)popc64((W2 ^ S2) & lowm);
+                    id[11] = r3.x + b0 + (r3.y >> 16) + (u32)popc64((W3 ^ S3) & lowm);
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) s_ids[tid][e] = id[e];
+                }
+            }
             const u32 nt = s_ntri[mask];
             u32 batch_total;
             const u32 o = block_excl_scan(nt, s_tmp, &batch_total);  // (its barriers order the LDS reuse)
             s_cmask[tid] = (unsigned char)mask;
             for (u32 k = 0; k < nt; ++k) s_tri[o + k] = (unsigned short)((tid << 3) | k);
             __syncthreads();
+            // phase D (lane = triangle)
             for (u32 tix = tid; tix < batch_total; tix += kBlock) {
                 const int ref = s_tri[tix];
                 const int ci = ref >> 3, k = ref & 7;
-                const int cell = s_cells[i0 + ci];
-                const int tu = cell >> 6, z = cell & 63;
-                const u64 row = s_tab[s_cmask[ci]];
-                const int64_t pt = tile * kBlock + tu;
-                const int cc = (int)(pt % d.ncz);
-                const int64_t pu = x * d.P + pt;
-                const int64_t ucol[4] = {pu, pu + d.P, pu + d.P + d.ncz, pu + d.ncz};
+                const u32 row3 = (u32)(s_tab[s_cmask[ci]] >> (12 * k));
                 const int64_t f = (int64_t)run + tix;
                 if (f < cap_faces) {
                     int32_t* o3 = faces + f * 3;
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const int e = (int)((row >> (4 * (3 * k + q))) & 0xF);
-                        o3[q] = (int32_t)edge_vertex_id(e, s_w, s_r, tu, z, cc, d.ncz, ucol, rec, xhalo, a);
-                    }
+                    o3[0] = (int32_t)s_ids[ci][row3 & 15u];
+                    o3[1] = (int32_t)s_ids[ci][(row3 >> 4) & 15u];
+                    o3[2] = (int32_t)s_ids[ci][(row3 >> 8) & 15u];
                 }
             }
             run += batch_total;
