@@ -28,6 +28,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
 
 #include "../../include/p3d_mc.h"
@@ -87,14 +88,16 @@ Ws make_ws(const Dims& d) {
     o = align_up(o + (size_t)(d.U + 2) * 8, 256);
     w.cnt = o;
     o = align_up(o + (size_t)d.U * 4, 256);
+    // scan arrays: padded to 1024 runs of a multiple of 4 entries (k_scan_blocks reads/writes whole runs)
+    auto scan_pad = [](int64_t nb) { return (size_t)(((nb + 1023) / 1024 + 3) / 4 * 4) * 1024 + 16; };
     w.bsum_v = o;
-    o = align_up(o + (size_t)w.nb_v * 4, 256);
+    o = align_up(o + scan_pad(w.nb_v) * 4, 256);
     w.bbase_v = o;
-    o = align_up(o + (size_t)w.nb_v * 4, 256);
+    o = align_up(o + scan_pad(w.nb_v) * 4, 256);
     w.bsum_f = o;
-    o = align_up(o + (size_t)(w.nb_f + 1) * 4, 256);
+    o = align_up(o + scan_pad(w.nb_f) * 4, 256);
     w.bbase_f = o;
-    o = align_up(o + (size_t)(w.nb_f + 1) * 4, 256);
+    o = align_up(o + scan_pad(w.nb_f) * 4, 256);
     w.total = o;
     return w;
 }
@@ -233,15 +236,22 @@ __global__ void __launch_bounds__(kBlock) k_unit_counts(const u64* __restrict__ 
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
 
-// exclusive scan of block sums by ONE block of 1024 threads: each thread owns a contiguous run
+// exclusive scan of block sums by ONE block of 1024 threads.  Thread t owns the contiguous run
+// [t*per, (t+1)*per), per a multiple of 4: 16-byte loads with no dependence between them, one block-wide scan of
+// the run totals, 16-byte stores.  The arrays are padded to 1024*per entries (make_ws).
 __global__ void __launch_bounds__(1024) k_scan_blocks(const u32* __restrict__ bsum, u32* __restrict__ bbase,
                                                       int64_t nb, u64* __restrict__ total_out) {
     __shared__ u64 s_w[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t per = (nb + 1023) / 1024;
-    const int64_t i0 = (int64_t)tid * per, i1 = (i0 + per < nb) ? i0 + per : nb;
+    const int64_t per = ((nb + 1023) / 1024 + 3) / 4 * 4;
+    const int64_t i0 = (int64_t)tid * per;
+    const uint4* src = (const uint4*)(bsum + i0);
     u64 sum = 0;
-    for (int64_t i = i0; i < i1; ++i) sum += bsum[i];
+    for (int64_t q = 0; q < per / 4; ++q) {
+        const uint4 v = src[q];
+        const int64_t i = i0 + q * 4;
+        sum += (i < nb ? v.x : 0u) + (u64)(i + 1 < nb ? v.y : 0u) + (i + 2 < nb ? v.z : 0u) + (i + 3 < nb ? v.w : 0u);
+    }
     u64 inc = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -257,9 +267,20 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(const u32* __restrict__ bs
         total += s_w[w];
     }
     u64 run = wbase + inc - sum;
-    for (int64_t i = i0; i < i1; ++i) {
-        bbase[i] = (u32)(run > 0xffffffffull ? 0xffffffffull : run);
-        run += bsum[i];
+    uint4* dst = (uint4*)(bbase + i0);
+    for (int64_t q = 0; q < per / 4; ++q) {
+        const uint4 v = src[q];
+        const int64_t i = i0 + q * 4;
+        uint4 o;
+        o.x = (u32)(run > 0xffffffffull ? 0xffffffffull : run);
+        run += (i < nb ? v.x : 0u);
+        o.y = (u32)(run > 0xffffffffull ? 0xffffffffull : run);
+        run += (i + 1 < nb ? v.y : 0u);
+        o.z = (u32)(run > 0xffffffffull ? 0xffffffffull : run);
+        run += (i + 2 < nb ? v.z : 0u);
+        o.w = (u32)(run > 0xffffffffull ? 0xffffffffull : run);
+        run += (i + 3 < nb ? v.w : 0u);
+        dst[q] = o;
     }
     if (tid == 0) *total_out = total;
 }
@@ -729,6 +750,30 @@ Xform make_xform(const Dims& d, const float lower[3], const float upper[3], cons
     return t;
 }
 
+// The region compaction (pure copy, bandwidth bound) does not feed the face pass (latency bound): it runs on a
+// side stream between two events so the two overlap.  One side stream + event pair per device, created lazily.
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+SideStream* side_stream_for_current_device() {
+    static SideStream tab[64];
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    SideStream& s = tab[dev];
+    if (!s.stream) {
+        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) {
+            s.stream = nullptr;
+            return nullptr;
+        }
+    }
+    return &s;
+}
+
 template <typename T>
 int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xform& t, const p3d_mc_slab* slab,
                char* ws, float* verts, int64_t capv, float* scratch, int64_t scratch_rows, int32_t* faces,
@@ -755,9 +800,19 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         hipLaunchKernelGGL(k_region_prefix, dim3(1), dim3(64), 0, st, hdr, cursors, prefix,
                            scratch ? store_rows : region_rows);
         hipLaunchKernelGGL(k_fix_records, dim3((u32)w.nb_v), dim3(256), 0, st, rec, d.U, prefix, region_rows);
-        if (scratch && capv > 0)
-            hipLaunchKernelGGL(k_compact, dim3(64, kRegions), dim3(256), 0, st, scratch, cursors, prefix, store_rows,
-                               verts, capv);
+    }
+    SideStream* side = nullptr;
+    if (scratch && capv > 0) {
+        side = env_int("P3D_NO_SIDE_STREAM", 0) ? nullptr : side_stream_for_current_device();
+        hipStream_t cs = st;
+        if (side) {
+            HIP_TRY(hipEventRecord(side->fork, st));
+            HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
+            cs = side->stream;
+        }
+        hipLaunchKernelGGL(k_compact, dim3(64, kRegions), dim3(256), 0, cs, scratch, cursors, prefix, store_rows, verts,
+                           capv);
+        if (side) HIP_TRY(hipEventRecord(side->join, side->stream));
     }
     FaceArgs a{halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0, w.tpp};
     if (w.nb_f > 0) {
@@ -774,6 +829,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         hipLaunchKernelGGL(k_faces<true>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, bbf, bsf, faces,
                            capf);
     }
+    if (side) HIP_TRY(hipStreamWaitEvent(st, side->join, 0));  // the caller's stream owns both outputs again
     HIP_TRY(hipGetLastError());
     return P3D_OK;
 }
