@@ -49,10 +49,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # dev-only overrides to dry-run the N>1 code path on a 1-GPU box: all ranks on cuda:0, gloo transport
+    share = os.environ.get("P3D_BENCH_SHARE_DEVICE") == "1"
+    backend = os.environ.get("P3D_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import primitive3d_amd as p3d
     from primitive3d_amd import capi
@@ -64,6 +71,8 @@ def main():
         if world not in SHAPES:
             sys.exit(f"unsupported world size {world}")
         shape = SHAPES[world]
+        if args.size:  # dev: smaller dry-run volume, cubic per rank
+            shape = (args.size * world, args.size, args.size)
     rx, ry, rz = shape
     thresh = 0.0
     lower, upper = [0.0, 0.0, 0.0], [float(rx), float(ry), float(rz)]
@@ -130,7 +139,7 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         tfile = ROOT / "profiles" / "traffic.json"
-        if tfile.exists():
+        if tfile.exists() and world == 1 and shape == SHAPES[1]:  # measured for this exact workload only
             try:
                 traffic = json.loads(tfile.read_text()).get("k_fused_hbm_bytes_per_launch")
             except Exception:

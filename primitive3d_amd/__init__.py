@@ -14,10 +14,11 @@ if not capi_path().exists() or not pybind_path().exists():
         "or `__graft_entry__.build()`. There is no fallback path.")
 
 from . import libPrim3D  # noqa: E402  (pybind adapter over the C ABI)
-from .marching_cubes import marching_cubes, save_mesh, scale_to_bound  # noqa: E402
+from .marching_cubes import marching_cubes, marching_cubes_batched, save_mesh, scale_to_bound  # noqa: E402
 from .misc import Timer  # noqa: E402
 
 __version__ = "0.1.0"
 ENABLE_OPTIX = libPrim3D.enable_optix
 
-__all__ = ["__version__", "ENABLE_OPTIX", "Timer", "marching_cubes", "save_mesh", "scale_to_bound", "libPrim3D"]
+__all__ = ["__version__", "ENABLE_OPTIX", "Timer", "marching_cubes", "marching_cubes_batched", "save_mesh",
+           "scale_to_bound", "libPrim3D"]

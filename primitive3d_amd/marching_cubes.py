@@ -102,3 +102,39 @@ def save_mesh(
         raise NotImplementedError()
     if verbose:
         print(f"save as {filename} successfully!")
+
+
+def marching_cubes_batched(density_grids, thresh: float, scale=None):
+    """Per-frame extraction of a batch of grids (BASELINE.json config 5: NeRF-style density grids).
+
+    NOT in the reference (its C++ entry rejects 4-D input, marching_cubes.cu:219, and its wrapper
+    up-casts to fp32, marching_cubes.py:87): `density_grids` is a [B, rx, ry, rz] CUDA tensor of
+    float32 **or float16**; fp16 grids are read as fp16 (half the HBM bytes) and compared in fp32,
+    which is exactly the reference applied to `density_grids[b].float()` (the conversion is exact).
+    Returns (vertices [sumV,3] f32, faces [sumF,3] i32 with per-item LOCAL vertex ids,
+    vertex_offsets [B+1] i64, face_offsets [B+1] i64).
+    """
+    from . import capi
+    if isinstance(density_grids, np.ndarray):
+        density_grids = torch.tensor(density_grids)
+    density_grids = density_grids.cuda()
+    if density_grids.dtype not in (torch.float16, torch.float32):
+        density_grids = density_grids.to(torch.float32)
+    if density_grids.dim() != 4 or min(density_grids.shape[1:]) < 2:
+        raise ValueError()
+    shape = density_grids.shape[1:]
+    if scale is None:
+        lower, upper = [0.0, 0.0, 0.0], [shape[0], shape[1], shape[2]]
+    else:
+        lower, upper = scale_to_bound(scale)
+    vs, fs, cap = [], [], None
+    for b in range(density_grids.shape[0]):
+        g = density_grids[b].contiguous()
+        v, f = capi.extract_fused(g, thresh, lower, upper, cap_vertices=cap[0] if cap else None,
+                                  cap_faces=cap[1] if cap else None)
+        cap = (v.shape[0] + v.shape[0] // 8 + 4096, f.shape[0] + f.shape[0] // 8 + 4096)  # next frame's size hint
+        vs.append(v)
+        fs.append(f)
+    voff = torch.tensor([0] + [v.shape[0] for v in vs], dtype=torch.int64).cumsum(0)
+    foff = torch.tensor([0] + [f.shape[0] for f in fs], dtype=torch.int64).cumsum(0)
+    return torch.cat(vs), torch.cat(fs), voff, foff

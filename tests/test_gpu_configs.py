@@ -1,0 +1,96 @@
+"""BASELINE.json configurations at their full sizes, checked through size-independent properties and
+an independent on-device count (plain torch ops, no code shared with the HIP kernels)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_count
+from oracle.np_counts import tri_counts
+
+pytestmark = pytest.mark.gpu
+
+
+def torch_counts(g, thresh):
+    """V and F as count_vertices_faces_kernel defines them (marching_cubes.cu:25-66), with torch ops."""
+    ins = g.float() > thresh
+    v = int((ins[1:] != ins[:-1]).sum() + (ins[:, 1:] != ins[:, :-1]).sum() + (ins[:, :, 1:] != ins[:, :, :-1]).sum())
+    c = ins.to(torch.int16)
+    sx, sy, sz = (s - 1 for s in g.shape)
+    corners = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)]
+    mask = torch.zeros((sx, sy, sz), dtype=torch.int16, device=g.device)
+    for bit, (dx, dy, dz) in enumerate(corners):
+        mask |= c[dx:dx + sx, dy:dy + sy, dz:dz + sz] << bit
+    nt = torch.from_numpy(tri_counts()).to(g.device)
+    f = int(nt[mask.long()].sum())
+    return v, f
+
+
+def mesh_properties(v, f):
+    assert f.min() >= 0 and f.max() < v.shape[0]
+    used = torch.zeros(v.shape[0], dtype=torch.bool, device=v.device)
+    used[f.flatten().long()] = True
+    assert bool(used.all()), "every vertex is referenced by some triangle"
+    # every directed edge is used by at most one triangle (consistent winding, no duplicated faces)
+    fl = f.long()
+    e = torch.cat([fl[:, [0, 1]], fl[:, [1, 2]], fl[:, [2, 0]]])
+    key = e[:, 0] * v.shape[0] + e[:, 1]
+    ne = e[:, 0] != e[:, 1]
+    assert bool(ne.all())
+    assert key.unique().numel() == key.numel()
+    assert bool(torch.isfinite(v).all())
+
+
+def test_c3_perlin_512_full_size(gpu, built):
+    from primitive3d_amd.fields import perlin_grid
+    g = perlin_grid(512, period=64, seed=0, device=gpu)
+    v, f = built.marching_cubes(g, 0.0)
+    ev, ef = torch_counts(g, 0.0)
+    assert (v.shape[0], f.shape[0]) == (ev, ef)
+    mesh_properties(v, f)
+    assert float(v.min()) >= 0.0 and float(v.max()) <= 511.0
+    # a second call (size hints now known) must give the same mesh up to order: compare sorted positions
+    v2, f2 = built.marching_cubes(g, 0.0)
+    assert v2.shape == v.shape and f2.shape == f.shape
+    a = torch.sort(v.double() @ torch.tensor([1.0, 1e3, 1e6], dtype=torch.float64, device=gpu)).values
+    b = torch.sort(v2.double() @ torch.tensor([1.0, 1e3, 1e6], dtype=torch.float64, device=gpu)).values
+    assert torch.equal(a, b)
+
+
+def test_c2_bunny_resampled_256(gpu, built):
+    """bunny.npy (66^3) trilinearly resampled to 256^3 as SURVEY.md section 8d defines C2; native 66^3 counts too."""
+    from pathlib import Path
+    b = torch.from_numpy(np.load(Path(__file__).parent / "golden" / "bunny66.npy"))
+    v, f = built.marching_cubes(b.to(gpu), 0.0)
+    assert (v.shape[0], f.shape[0]) == (13282, 26560)
+    big = torch.nn.functional.interpolate(b[None, None], size=(256,) * 3, mode="trilinear", align_corners=True)[0, 0]
+    v, f = built.marching_cubes(big.to(gpu), 0.0)
+    assert (v.shape[0], f.shape[0]) == oracle_count(big.numpy(), 0.0) == torch_counts(big.to(gpu), 0.0)
+    mesh_properties(v, f)
+    # the bunny SDF is closed inside the grid: Euler characteristic 2
+    e = torch.cat([f.long()[:, [0, 1]], f.long()[:, [1, 2]], f.long()[:, [2, 0]]]).sort(dim=1).values
+    n_e = (e[:, 0] * v.shape[0] + e[:, 1]).unique().numel()
+    assert v.shape[0] - n_e + f.shape[0] == 2
+
+
+def test_c5_batched_fp16(gpu, built):
+    """config 5 at reduced batch for the oracle comparison, full item size property check for one item"""
+    from primitive3d_amd.fields import perlin_grid
+    from oracle import canonical_mesh, oracle_extract  # noqa: F401
+    grids = torch.stack([perlin_grid(48, period=16, seed=s) for s in range(3)]).half()
+    v, f, vo, fo = built.marching_cubes_batched(grids.to(gpu), 0.0)
+    assert vo.shape == (4,) and fo.shape == (4,) and int(vo[-1]) == v.shape[0] and int(fo[-1]) == f.shape[0]
+    for b in range(3):
+        ev, ef = oracle_count(grids[b].float().numpy(), 0.0)
+        assert int(vo[b + 1] - vo[b]) == ev and int(fo[b + 1] - fo[b]) == ef
+        fb = f[fo[b]:fo[b + 1]]
+        assert fb.numel() == 0 or (int(fb.min()) >= 0 and int(fb.max()) < ev)
+    big = perlin_grid(256, period=64, seed=7, device=gpu).half()
+    v, f, vo, fo = built.marching_cubes_batched(big[None], 0.0)
+    assert (v.shape[0], f.shape[0]) == torch_counts(big, 0.0)
+    mesh_properties(v, f)
+
+
+def test_c1_sphere64_through_wrapper(gpu, built):
+    from primitive3d_amd.fields import sphere_grid
+    v, f = built.marching_cubes(sphere_grid(64), 0)  # int64 ndarray, like examples/sphere.py
+    assert (v.shape[0], f.shape[0]) == (1182, 2360)
