@@ -137,7 +137,7 @@ def profile_read():
 def scratch_rows_for(cap_vertices: int) -> int:
     """Rows of vertex scratch for an expected vertex count: 32 regions, 25 % + 256 rows of slack each."""
     per = (cap_vertices + 31) // 32
-    return 32 * (per + per // 4 + 256)
+    return 32 * max(per + per // 4 + 256, min(cap_vertices, 8192))  # small outputs may land in very few regions
 
 
 def extract_fused_raw(grid, thresh, lower, upper, ws, vertices, faces, slab=None, full_res=None, scratch=None):

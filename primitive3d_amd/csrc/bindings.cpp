@@ -99,8 +99,9 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     vertices = torch::empty({capv, 3}, vopt);
     faces = torch::empty({capf, 3}, fopt);
     // vertex scratch: 32 independently filled regions (25 % + 256 rows of slack each); freed on return
+    // (small outputs may all come from a few wave-planes, i.e. a few regions: every region can hold 8192 rows)
     const int64_t per_region = (capv + 31) / 32;
-    const int64_t scratch_rows = 32 * (per_region + per_region / 4 + 256);
+    const int64_t scratch_rows = 32 * std::max<int64_t>(per_region + per_region / 4 + 256, std::min<int64_t>(capv, 8192));
     Tensor scratch = torch::empty({scratch_rows, 3}, vopt);
     check_rc(p3d_mc_extract_fused(grid, P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, nullptr,
                                   ws.data_ptr(), vertices.data_ptr<float>(), capv, scratch.data_ptr<float>(),

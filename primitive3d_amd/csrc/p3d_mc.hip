@@ -709,11 +709,21 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
     FusedGeom g;
     g.nzt = (d.ncz + NC - 1) / NC;
     g.nyt = (int)((d.ry + kFusedWPB * RY - 1) / (kFusedWPB * RY));
-    // enough blocks to fill the chip a few times over, but planes per block >= 8 (x-halo overhead 1/XT)
+    // planes per block: enough blocks to fill the chip a few times over, but >= 8 planes (x-halo overhead 1/XT)
+    // unless the grid is so small that 8-plane blocks would leave most CUs idle (then latency wins over the halo)
     const int64_t per_slab = (int64_t)g.nzt * g.nyt;
     int64_t want_slabs = (env_int("P3D_FUSED_BLOCKS", 4096) + per_slab - 1) / per_slab;
     int xt = (int)((d.rx + want_slabs - 1) / want_slabs);
-    xt = env_int("P3D_FUSED_XT", xt < 8 ? 8 : xt);
+    if (xt < 8) {
+        const int64_t blocks_at_8 = per_slab * ((d.rx + 7) / 8);
+        if (blocks_at_8 >= 1024) xt = 8;
+        else {
+            const int64_t slabs_for_1024 = (1024 + per_slab - 1) / per_slab;
+            xt = (int)std::max<int64_t>(1, std::min<int64_t>(8, (d.rx + slabs_for_1024 - 1) / slabs_for_1024));
+        }
+    }
+    xt = env_int("P3D_FUSED_XT", xt);
+    if (xt < 1) xt = 1;
     if (xt > d.rx) xt = (int)d.rx;
     g.XT = xt;
     g.nxt = (int)((d.rx + xt - 1) / xt);
