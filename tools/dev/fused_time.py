@@ -21,7 +21,7 @@ for i in range(8):
 print(os.environ.get("P3D_CAPI_LIB", "default"), "V", nv, "F", nf, {k: round(t * 1e3, 1) for k, t in acc.items()}, "us")
 if os.environ.get("STAMPS"):
     h = ws[:8192].cpu().numpy().view("uint64")
-    seg = h[640:648].astype(float)
-    names = ["prefetch issue", "make_words(+load wait)", "bookkeeping", "atomic+bits", "vinfo fill", "vertex batches", "rec/post", "store_plane+loop"]
+    seg = h[640:644].astype(float)
+    names = ["make_words(+load wait)", "bookkeeping+bits+atomic issue+misc", "vertex work (vinfo, batches, stores, rec)", "prefetch issue + store_plane + loop"]
     tot = seg.sum()
     print("stamps (share of wave cycles):", {n: f"{100*v/tot:.1f}%" for n, v in zip(names, seg)}, "cycles/wave-step", round(tot / 88064))
