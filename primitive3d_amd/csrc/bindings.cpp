@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -80,6 +82,9 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
         return {vertices, faces};
     }
 
+    static const bool host_trace = std::getenv("P3D_HOST_TRACE") != nullptr;
+    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_in = host_trace ? now_us() : 0.0;
     // one-pass: the field is streamed ONCE into output buffers sized from the last call on a grid of this
     // shape (or from a density guess the first time); the true counts come back with the data.  If the guess
     // was too small the ids already assigned stay valid and only the emission is redone into exact buffers.
@@ -103,12 +108,21 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     const int64_t per_region = (capv + 31) / 32;
     const int64_t scratch_rows = 32 * std::max<int64_t>(per_region + per_region / 4 + 256, std::min<int64_t>(capv, 8192));
     Tensor scratch = torch::empty({scratch_rows, 3}, vopt);
+    const double t_alloc = host_trace ? now_us() : 0.0;
     check_rc(p3d_mc_extract_fused(grid, P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, nullptr,
                                   ws.data_ptr(), vertices.data_ptr<float>(), capv, scratch.data_ptr<float>(),
                                   scratch_rows, faces.data_ptr<int32_t>(), capf, stream),
              "p3d_mc_extract_fused");
+    const double t_enq = host_trace ? now_us() : 0.0;
     int32_t overflow = 0;
     check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, &overflow, stream), "p3d_mc_read_counts");
+    if (host_trace) {
+        static double t_prev_out = 0.0;
+        const double t_sync = now_us();
+        fprintf(stderr, "[p3d host] since-prev-return %.1f  alloc %.1f  enqueue %.1f  wait+read %.1f us\n",
+                t_prev_out ? t_in - t_prev_out : 0.0, t_alloc - t_in, t_enq - t_alloc, t_sync - t_enq);
+        t_prev_out = t_sync;
+    }
     {
         std::lock_guard<std::mutex> g(g_cap_mu);
         g_cap_hint[key] = {nv, nf};

@@ -764,7 +764,7 @@ Xform make_xform(const Dims& d, const float lower[3], const float upper[3], cons
 // side stream between two events so the two overlap.  One side stream + event pair per device, created lazily.
 struct SideStream {
     hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t fork = nullptr, fixed = nullptr, join = nullptr;
 };
 SideStream* side_stream_for_current_device() {
     static SideStream tab[64];
@@ -776,6 +776,7 @@ SideStream* side_stream_for_current_device() {
     if (!s.stream) {
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.fixed, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) {
             s.stream = nullptr;
             return nullptr;
@@ -805,25 +806,28 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         const int64_t xo = slab ? slab->x_origin : 0;
         dispatch_fused<T>(grid, d, thresh, halo, t, xo, bits, rec, cursors, scratch, region_rows, store_rows, st);
     }
+    // After the streaming kernel two independent chains run side by side:
+    //   side stream : region prefix -> dense ids in rec[] (k_fix_records) -> compaction of the vertex regions
+    //   main stream : face count (needs only the sign words) -> scan -> [ids fixed] -> face emission
+    SideStream* side = env_int("P3D_NO_SIDE_STREAM", 0) ? nullptr : side_stream_for_current_device();
+    hipStream_t fs = st;  // stream of the finalize chain
+    if (side) {
+        HIP_TRY(hipEventRecord(side->fork, st));
+        HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
+        fs = side->stream;
+    }
     {
-        StageTimer tm(ST_FINALIZE, st);
-        hipLaunchKernelGGL(k_region_prefix, dim3(1), dim3(64), 0, st, hdr, cursors, prefix,
+        StageTimer tm(ST_FINALIZE, fs);
+        hipLaunchKernelGGL(k_region_prefix, dim3(1), dim3(64), 0, fs, hdr, cursors, prefix,
                            scratch ? store_rows : region_rows);
-        hipLaunchKernelGGL(k_fix_records, dim3((u32)w.nb_v), dim3(256), 0, st, rec, d.U, prefix, region_rows);
+        hipLaunchKernelGGL(k_fix_records, dim3((u32)w.nb_v), dim3(256), 0, fs, rec, d.U, prefix, region_rows);
     }
-    SideStream* side = nullptr;
-    if (scratch && capv > 0) {
-        side = env_int("P3D_NO_SIDE_STREAM", 0) ? nullptr : side_stream_for_current_device();
-        hipStream_t cs = st;
-        if (side) {
-            HIP_TRY(hipEventRecord(side->fork, st));
-            HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
-            cs = side->stream;
-        }
-        hipLaunchKernelGGL(k_compact, dim3(64, kRegions), dim3(256), 0, cs, scratch, cursors, prefix, store_rows, verts,
+    if (side) HIP_TRY(hipEventRecord(side->fixed, fs));
+    if (scratch && capv > 0)
+        hipLaunchKernelGGL(k_compact, dim3(64, kRegions), dim3(256), 0, fs, scratch, cursors, prefix, store_rows, verts,
                            capv);
-        if (side) HIP_TRY(hipEventRecord(side->join, side->stream));
-    }
+    if (side) HIP_TRY(hipEventRecord(side->join, fs));
+
     FaceArgs a{halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0, w.tpp};
     if (w.nb_f > 0) {
         StageTimer tm(ST_FACES_COUNT, st);
@@ -834,6 +838,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         StageTimer tm(ST_SCAN_F, st);
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, bsf, bbf, w.nb_f, hdr + H_T);
     }
+    if (side) HIP_TRY(hipStreamWaitEvent(st, side->fixed, 0));
     if (w.nb_f > 0 && capf > 0 && !(slab && slab->halo_last_plane)) {
         StageTimer tm(ST_EMIT_FACES, st);
         hipLaunchKernelGGL(k_faces<true>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, bbf, bsf, faces,
