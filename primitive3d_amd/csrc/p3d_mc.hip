@@ -726,7 +726,15 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
     if (xt < 1) xt = 1;
     if (xt > d.rx) xt = (int)d.rx;
     g.XT = xt;
-    g.nxt = (int)((d.rx + xt - 1) / xt);
+    // taper: the last ~1/8 of the planes go in slabs of XT/4 planes
+    const int xt_tail = env_int("P3D_FUSED_XT_TAIL", xt >= 4 ? xt / 4 : xt);
+    const int64_t nslab_all = (d.rx + xt - 1) / xt;
+    int64_t n_big = nslab_all - std::max<int64_t>(1, nslab_all / env_int("P3D_FUSED_TAIL_DIV", 4));
+    if (xt_tail >= xt || nslab_all < 8) n_big = nslab_all;
+    g.n_big = (int)n_big;
+    g.XT_tail = xt_tail > 0 ? xt_tail : 1;
+    const int64_t rest = d.rx - n_big * xt;
+    g.nxt = (int)(n_big + (rest > 0 ? (rest + g.XT_tail - 1) / g.XT_tail : 0));
     const int64_t nblocks = per_slab * g.nxt;
     hipLaunchKernelGGL((k_fused<T, NC, RY>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, grid, thresh, d, g, halo, t,
                        x_origin, bits, rec, cursors, scratch, region_rows, store_rows);
