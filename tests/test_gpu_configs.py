@@ -94,3 +94,20 @@ def test_c1_sphere64_through_wrapper(gpu, built):
     from primitive3d_amd.fields import sphere_grid
     v, f = built.marching_cubes(sphere_grid(64), 0)  # int64 ndarray, like examples/sphere.py
     assert (v.shape[0], f.shape[0]) == (1182, 2360)
+
+
+def test_c4_shape_two_slabs_of_1024_squared(gpu):
+    """config 4's per-rank shape (128 planes of 1024^2 + halo) for two neighbouring ranks, run in one process:
+    counts against the independent torch count of the 256x1024x1024 grid, global face ids in range, and the
+    vertices both slabs produce lie in their own x ranges."""
+    from primitive3d_amd.fields import perlin_grid
+    from primitive3d_amd.slab import extract_in_process
+    g = perlin_grid((256, 1024, 1024), period=64, seed=0, device=gpu)
+    res = extract_in_process(g, 2, 0.0)
+    torch.cuda.synchronize()
+    ev, ef = torch_counts(g, 0.0)
+    assert sum(r.vertices.shape[0] for r in res) == ev and sum(r.faces.shape[0] for r in res) == ef
+    v = torch.cat([r.vertices for r in res])
+    f = torch.cat([r.faces for r in res])
+    mesh_properties(v, f)
+    assert float(res[0].vertices[:, 0].max()) < 128.0 and float(res[1].vertices[:, 0].min()) >= 128.0

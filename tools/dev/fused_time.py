@@ -5,14 +5,15 @@ import torch
 from primitive3d_amd import capi
 from primitive3d_amd.fields import perlin_grid
 n = int(os.environ.get("N", "512"))
-g = perlin_grid(n, device="cuda")
-ws = torch.empty(capi.workspace_bytes(n, n, n), dtype=torch.uint8, device="cuda")
-capv = n ** 3 // 16
+shape = tuple(int(v) for v in os.environ["SHAPE"].split(",")) if os.environ.get("SHAPE") else (n, n, n)
+g = perlin_grid(shape, device="cuda")
+ws = torch.empty(capi.workspace_bytes(*shape), dtype=torch.uint8, device="cuda")
+capv = shape[0] * shape[1] * shape[2] // 16
 v = torch.empty((capv, 3), device="cuda"); f = torch.empty((2 * capv, 3), dtype=torch.int32, device="cuda")
 capi.profile_enable(2)
 acc = {}
 for i in range(8):
-    capi.extract_fused_raw(g, 0.0, [0, 0, 0], [n, n, n], ws, v, f)
+    capi.extract_fused_raw(g, 0.0, [0, 0, 0], list(shape), ws, v, f)
     nv, nf = capi.read_counts(ws)
     torch.cuda.synchronize()
     st = capi.profile_read()
