@@ -69,28 +69,40 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
         const char* m = std::getenv("P3D_MC_MODE");
         return m && std::string(m) == "exact";
     }();
-    if (exact_mode) {
-        // two-phase: count (reads the field), host sync, exact allocation, emit (reads the active part again)
-        check_rc(p3d_mc_count(grid, P3D_F32, rx, ry, rz, thresh, nullptr, ws.data_ptr(), stream), "p3d_mc_count");
-        check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, nullptr, stream), "p3d_mc_read_counts");
-        vertices = torch::empty({nv, 3}, vopt);
-        faces = torch::empty({nf, 3}, fopt);
-        check_rc(p3d_mc_emit(grid, P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, nullptr,
-                             ws.data_ptr(), nv ? vertices.data_ptr<float>() : nullptr, nv,
-                             nf ? faces.data_ptr<int32_t>() : nullptr, nf, nullptr, stream),
-                 "p3d_mc_emit");
-        return {vertices, faces};
-    }
-
     static const bool host_trace = std::getenv("P3D_HOST_TRACE") != nullptr;
     auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_in = host_trace ? now_us() : 0.0;
-    // one-pass: the field is streamed ONCE into output buffers sized from the last call on a grid of this
-    // shape (or from a density guess the first time); the true counts come back with the data.  If the guess
-    // was too small the ids already assigned stay valid and only the emission is redone into exact buffers.
+
+    // One streaming pass into buffers of the given capacities (0,0 = count only).  The vertex scratch is cut into
+    // 32 independently filled regions: `slack` is the headroom per region, and every region can hold 8192 rows
+    // because a small output may come from very few wave-planes.  Returns true when everything fitted.
+    auto run_pass = [&](int64_t capv, int64_t capf, int64_t slack_num, int64_t slack_den) {
+        Tensor scratch;
+        int64_t scratch_rows = 0;
+        if (capv > 0) {
+            const int64_t per_region = (capv + 31) / 32;
+            scratch_rows = 32 * std::max<int64_t>(per_region * slack_num / slack_den + 256, std::min<int64_t>(capv, 8192));
+            scratch = torch::empty({scratch_rows, 3}, vopt);
+            vertices = torch::empty({capv, 3}, vopt);
+        }
+        if (capf > 0) faces = torch::empty({capf, 3}, fopt);
+        check_rc(p3d_mc_extract_fused(grid, P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, nullptr,
+                                      ws.data_ptr(), capv ? vertices.data_ptr<float>() : nullptr, capv,
+                                      capv ? scratch.data_ptr<float>() : nullptr, scratch_rows,
+                                      capf ? faces.data_ptr<int32_t>() : nullptr, capf, stream),
+                 "p3d_mc_extract_fused");
+        int32_t overflow = 0;
+        check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, &overflow, stream), "p3d_mc_read_counts");
+        return nv <= capv && nf <= capf && !overflow;
+    };
+
+    // Output sizes: the reference counts first (marching_cubes.cu:242-252).  Here the default is to guess them from
+    // the last call on a grid of this shape (first call: a density guess), stream the field ONCE, and only if the
+    // guess was too small stream it a second time into exactly sized buffers.  P3D_MC_MODE=exact always does the
+    // reference's two steps (count pass, then an exactly sized pass).
     const CapKey key{dev.index(), rx, ry, rz};
-    int64_t capv, capf;
-    {
+    int64_t capv = 0, capf = 0;
+    if (!exact_mode) {
         std::lock_guard<std::mutex> g(g_cap_mu);
         auto it = g_cap_hint.find(key);
         if (it != g_cap_hint.end()) {
@@ -101,39 +113,32 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
             capf = 2 * capv;
         }
     }
-    vertices = torch::empty({capv, 3}, vopt);
-    faces = torch::empty({capf, 3}, fopt);
-    // vertex scratch: 32 independently filled regions (25 % + 256 rows of slack each); freed on return
-    // (small outputs may all come from a few wave-planes, i.e. a few regions: every region can hold 8192 rows)
-    const int64_t per_region = (capv + 31) / 32;
-    const int64_t scratch_rows = 32 * std::max<int64_t>(per_region + per_region / 4 + 256, std::min<int64_t>(capv, 8192));
-    Tensor scratch = torch::empty({scratch_rows, 3}, vopt);
-    const double t_alloc = host_trace ? now_us() : 0.0;
-    check_rc(p3d_mc_extract_fused(grid, P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, nullptr,
-                                  ws.data_ptr(), vertices.data_ptr<float>(), capv, scratch.data_ptr<float>(),
-                                  scratch_rows, faces.data_ptr<int32_t>(), capf, stream),
-             "p3d_mc_extract_fused");
-    const double t_enq = host_trace ? now_us() : 0.0;
-    int32_t overflow = 0;
-    check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, &overflow, stream), "p3d_mc_read_counts");
-    if (host_trace) {
-        static double t_prev_out = 0.0;
-        const double t_sync = now_us();
-        fprintf(stderr, "[p3d host] since-prev-return %.1f  alloc %.1f  enqueue %.1f  wait+read %.1f us\n",
-                t_prev_out ? t_in - t_prev_out : 0.0, t_alloc - t_in, t_enq - t_alloc, t_sync - t_enq);
-        t_prev_out = t_sync;
-    }
+    bool ok = run_pass(capv, capf, 5, 4);
     {
         std::lock_guard<std::mutex> g(g_cap_mu);
         g_cap_hint[key] = {nv, nf};
     }
-    if (nv > capv || nf > capf || overflow) {
-        vertices = torch::empty({nv, 3}, vopt);
-        faces = torch::empty({nf, 3}, fopt);
-        check_rc(p3d_mc_emit(grid, P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, nullptr,
-                             ws.data_ptr(), nv ? vertices.data_ptr<float>() : nullptr, nv,
-                             nf ? faces.data_ptr<int32_t>() : nullptr, nf, nullptr, stream),
-                 "p3d_mc_emit");
+    if (host_trace) {
+        static double t_prev_out = 0.0;
+        const double t_sync = now_us();
+        fprintf(stderr, "[p3d host] since-prev-return %.1f  first pass %.1f us (fitted: %d)\n",
+                t_prev_out ? t_in - t_prev_out : 0.0, t_sync - t_in, (int)ok);
+        t_prev_out = t_sync;
+    }
+    if (!ok || exact_mode) {
+        const int64_t ev = nv, ef = nf;  // exact sizes are known now
+        ok = run_pass(ev, ef, 2, 1);
+        if (!ok) {
+            // pathological region imbalance: the gather emitter writes by vertex id and cannot overflow
+            vertices = torch::empty({nv, 3}, vopt);
+            faces = torch::empty({nf, 3}, fopt);
+            check_rc(p3d_mc_emit(grid, P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, nullptr,
+                                 ws.data_ptr(), nv ? vertices.data_ptr<float>() : nullptr, nv,
+                                 nf ? faces.data_ptr<int32_t>() : nullptr, nf, nullptr, stream),
+                     "p3d_mc_emit");
+        }
+        if (nv == 0) vertices = torch::empty({0, 3}, vopt);
+        if (nf == 0) faces = torch::empty({0, 3}, fopt);
         return {vertices, faces};
     }
     // exact-size results: a view when the buffer is mostly used, a copy when the guess was generous
