@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define P3D_MC_ABI_VERSION 2
+#define P3D_MC_ABI_VERSION 3
 
 /* dtype of the scalar field */
 #define P3D_F32 0
@@ -52,10 +52,15 @@ typedef struct p3d_mc_slab {
                                 plane: its in-plane (axis 1/2) edges are owned by that rank, so no
                                 vertices are emitted for them and their index records are imported
                                 with p3d_mc_import_halo_records. */
-    int32_t reserved;
+    int32_t part;            /* p3d_mc_extract_fused only.  0: the whole slab in one call.
+                                1: stream planes [0, split_plane) and return (no finalize, no face pass) -- lets
+                                   the interior run while the halo plane is still in flight;
+                                2: continue with planes [split_plane, rx), then finalize and count faces.
+                                Parts 1 and 2 must be given the same buffers. */
     int64_t vertex_id_base;      /* added to every locally owned vertex id written into faces */
     int64_t halo_vertex_id_base; /* added to the imported records of the halo plane */
     int64_t x_origin;            /* global axis-0 index of local plane 0: vertex x = float(x_origin + x) + dt */
+    int64_t split_plane;         /* see `part` */
 } p3d_mc_slab;
 
 /* Bytes of device scratch p3d_mc_count / p3d_mc_emit need for an [rx,ry,rz] grid.

@@ -705,35 +705,40 @@ int env_int(const char* name, int dflt) {
 
 template <typename T, int NC, int RY>
 void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xform& t, int64_t x_origin, u64* bits,
-                  uint2* rec, u64* cursors, float* scratch, u32 region_rows, u32 store_rows, hipStream_t st) {
+                  uint2* rec, u64* cursors, float* scratch, u32 region_rows, u32 store_rows, int x_lo, int x_hi,
+                  hipStream_t st) {
     FusedGeom g;
+    g.x_lo = x_lo;
+    g.x_hi = x_hi;
+    const int64_t nplanes = x_hi - x_lo;
+    if (nplanes <= 0) return;
     g.nzt = (d.ncz + NC - 1) / NC;
     g.nyt = (int)((d.ry + kFusedWPB * RY - 1) / (kFusedWPB * RY));
     // planes per block: enough blocks to fill the chip a few times over, but >= 8 planes (x-halo overhead 1/XT)
     // unless the grid is so small that 8-plane blocks would leave most CUs idle (then latency wins over the halo)
     const int64_t per_slab = (int64_t)g.nzt * g.nyt;
     int64_t want_slabs = (env_int("P3D_FUSED_BLOCKS", 4096) + per_slab - 1) / per_slab;
-    int xt = (int)((d.rx + want_slabs - 1) / want_slabs);
+    int xt = (int)((nplanes + want_slabs - 1) / want_slabs);
     if (xt < 8) {
-        const int64_t blocks_at_8 = per_slab * ((d.rx + 7) / 8);
+        const int64_t blocks_at_8 = per_slab * ((nplanes + 7) / 8);
         if (blocks_at_8 >= 1024) xt = 8;
         else {
             const int64_t slabs_for_1024 = (1024 + per_slab - 1) / per_slab;
-            xt = (int)std::max<int64_t>(1, std::min<int64_t>(8, (d.rx + slabs_for_1024 - 1) / slabs_for_1024));
+            xt = (int)std::max<int64_t>(1, std::min<int64_t>(8, (nplanes + slabs_for_1024 - 1) / slabs_for_1024));
         }
     }
     xt = env_int("P3D_FUSED_XT", xt);
     if (xt < 1) xt = 1;
-    if (xt > d.rx) xt = (int)d.rx;
+    if (xt > nplanes) xt = (int)nplanes;
     g.XT = xt;
     // taper: the last ~1/8 of the planes go in slabs of XT/4 planes
     const int xt_tail = env_int("P3D_FUSED_XT_TAIL", xt >= 4 ? xt / 4 : xt);
-    const int64_t nslab_all = (d.rx + xt - 1) / xt;
+    const int64_t nslab_all = (nplanes + xt - 1) / xt;
     int64_t n_big = nslab_all - std::max<int64_t>(1, nslab_all / env_int("P3D_FUSED_TAIL_DIV", 4));
     if (xt_tail >= xt || nslab_all < 8) n_big = nslab_all;
     g.n_big = (int)n_big;
     g.XT_tail = xt_tail > 0 ? xt_tail : 1;
-    const int64_t rest = d.rx - n_big * xt;
+    const int64_t rest = nplanes - n_big * xt;
     g.nxt = (int)(n_big + (rest > 0 ? (rest + g.XT_tail - 1) / g.XT_tail : 0));
     const int64_t nblocks = per_slab * g.nxt;
     hipLaunchKernelGGL((k_fused<T, NC, RY>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, grid, thresh, d, g, halo, t,
@@ -742,7 +747,8 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
 
 template <typename T>
 void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xform& t, int64_t x_origin, u64* bits,
-                    uint2* rec, u64* cursors, float* scratch, u32 region_rows, u32 store_rows, hipStream_t st) {
+                    uint2* rec, u64* cursors, float* scratch, u32 region_rows, u32 store_rows, int x_lo, int x_hi,
+                    hipStream_t st) {
     // two tile geometries (both hold 32 unit words per wave-plane): long rows / short rows
 #ifdef P3D_EXP_GEOM47
     if (d.ncz >= 3)
@@ -750,9 +756,11 @@ void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const 
     else
 #endif
     if (d.ncz >= 3)
-        launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, scratch, region_rows, store_rows, st);
+        launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, scratch, region_rows, store_rows,
+                              x_lo, x_hi, st);
     else
-        launch_fused<T, 2, 15>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, scratch, region_rows, store_rows, st);
+        launch_fused<T, 2, 15>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, scratch, region_rows, store_rows,
+                               x_lo, x_hi, st);
 }
 
 Xform make_xform(const Dims& d, const float lower[3], const float upper[3], const int64_t full_res[3]) {
@@ -808,11 +816,20 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     // Storage is store_rows rows per region; without a scratch buffer nothing is stored (pure count + ids).
     const u32 region_rows = 1u << 26;
     const u32 store_rows = scratch ? (u32)std::min<int64_t>(scratch_rows / kRegions, (int64_t)region_rows) : 0u;
-    HIP_TRY(hipMemsetAsync(hdr, 0, kHdrBytes, st));
+    const int part = slab ? slab->part : 0;
+    int x_lo = 0, x_hi = (int)d.rx;
+    if (part == 1) x_hi = (int)slab->split_plane;
+    if (part == 2) x_lo = (int)slab->split_plane;
+    if (part != 2) HIP_TRY(hipMemsetAsync(hdr, 0, kHdrBytes, st));
     {
         StageTimer tm(ST_FUSED, st);
         const int64_t xo = slab ? slab->x_origin : 0;
-        dispatch_fused<T>(grid, d, thresh, halo, t, xo, bits, rec, cursors, scratch, region_rows, store_rows, st);
+        dispatch_fused<T>(grid, d, thresh, halo, t, xo, bits, rec, cursors, scratch, region_rows, store_rows, x_lo, x_hi,
+                          st);
+    }
+    if (part == 1) {  // the second part finalizes
+        HIP_TRY(hipGetLastError());
+        return P3D_OK;
     }
     // After the streaming kernel two independent chains run side by side:
     //   side stream : region prefix -> dense ids in rec[] (k_fix_records) -> compaction of the vertex regions
@@ -931,6 +948,8 @@ int p3d_mc_extract_fused(const void* grid, int dtype, int64_t rx, int64_t ry, in
     if (cap_vertices > 0 && (!vertex_scratch || scratch_rows < kRegions))
         return fail(P3D_EINVAL, "vertex output needs a scratch buffer of at least 32 rows%s");
     if (int rc = check_dims(rx, ry, rz)) return rc;
+    if (slab && slab->part != 0 && (slab->part < 0 || slab->part > 2 || slab->split_plane < 1 || slab->split_plane >= rx))
+        return fail(P3D_EINVAL, "bad slab part / split_plane%s");
     const Dims d = make_dims(rx, ry, rz);
     const Ws w = make_ws(d);
     const Xform t = make_xform(d, lower, upper, full_res);

@@ -48,23 +48,41 @@ class HipBackend:
         self._cap = None  # output-size hint from the previous call
         self._ws = None
 
-    def count_and_vertices(self, grid, thresh, lower, upper, full_res, x_origin, halo):
+    def _prepare(self, grid, x_origin, halo):
         c = self.capi
         rx, ry, rz = grid.shape
         nbytes = c.workspace_bytes(rx, ry, rz)
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        ws = self._ws
         capv = self._cap if self._cap is not None else max(4096, rx * ry * rz // 16)
-        self._slab = c.Slab(1 if halo else 0, 0, 0, 0, x_origin)
-        verts = torch.empty((capv, 3), dtype=torch.float32, device=self.device)
-        c.extract_fused_raw(grid, thresh, lower, upper, ws, verts, None, slab=self._slab, full_res=full_res)
+        self._verts = torch.empty((capv, 3), dtype=torch.float32, device=self.device)
+        self._scratch = torch.empty((c.scratch_rows_for(capv), 3), dtype=torch.float32, device=self.device)
+        self._mk = lambda part=0, split=0, vb=0, hb=0: c.Slab(1 if halo else 0, part, vb, hb, x_origin, split)
+
+    def begin_interior(self, grid, thresh, lower, upper, full_res, x_origin, halo, split):
+        """Stream planes [0, split): they do not touch the halo plane, so this can run while it is in flight."""
+        self._prepare(grid, x_origin, halo)
+        self._split = split
+        self.capi.extract_fused_raw(grid, thresh, lower, upper, self._ws, self._verts, None, slab=self._mk(1, split),
+                                    full_res=full_res, scratch=self._scratch)
+
+    def count_and_vertices(self, grid, thresh, lower, upper, full_res, x_origin, halo):
+        c = self.capi
+        split = getattr(self, "_split", 0)
+        if not split:
+            self._prepare(grid, x_origin, halo)
+        ws, verts = self._ws, self._verts
+        c.extract_fused_raw(grid, thresh, lower, upper, ws, verts, None, slab=self._mk(2 if split else 0, split),
+                            full_res=full_res, scratch=self._scratch)
+        self._split = 0
+        self._slab = self._mk()
         nv, nf, over = c.read_counts(ws, with_flags=True)
-        if nv > capv or over:  # guess too small: ids stay valid, redo only the vertex emission into an exact buffer
+        if nv > verts.shape[0] or over:  # guess too small: ids stay valid, redo only the vertex emission, exactly sized
             verts = torch.empty((nv, 3), dtype=torch.float32, device=self.device)
             c.emit(grid, thresh, lower, upper, ws, verts, None, slab=self._slab, full_res=full_res)
         self._cap = nv + nv // 8 + 4096
         self._state = (grid, thresh, lower, upper, full_res, ws, nf)
+        self._scratch = None
         return nv, nf, verts[:nv]
 
     def _plane_view(self, plane):
@@ -81,8 +99,7 @@ class HipBackend:
 
     def faces(self, vertex_id_base, halo_vertex_id_base):
         grid, thresh, lower, upper, full_res, ws, nf = self._state
-        s = self._slab
-        slab = self.capi.Slab(s.halo_last_plane, 0, vertex_id_base, halo_vertex_id_base, s.x_origin)
+        slab = self._mk(0, 0, vertex_id_base, halo_vertex_id_base)
         faces = torch.empty((nf, 3), dtype=torch.int32, device=self.device)
         self.capi.emit(grid, thresh, lower, upper, ws, None, faces, slab=slab, full_res=full_res)
         return faces
@@ -126,6 +143,18 @@ class SlabExtractor:
     def halo_recv_buffer(self) -> Optional[torch.Tensor]:
         return self.grid[self.n] if self.has_halo else None
 
+    def interior_split(self) -> int:
+        """First plane of the part that needs the halo plane (0 = do not split): the last 8 local planes."""
+        return self.n - 8 if (self.has_halo and self.n >= 24 and hasattr(self.backend, "begin_interior")) else 0
+
+    def phase_interior(self, thresh, lower, upper):
+        """Optional: start streaming the planes that do not depend on the halo plane."""
+        split = self.interior_split()
+        if split:
+            self.backend.begin_interior(self.grid, float(thresh), list(lower), list(upper), self.shape, self.x0,
+                                        self.has_halo, split)
+        return split
+
     def phase_extract(self, thresh, lower, upper):
         nv, nf, verts = self.backend.count_and_vertices(self.grid, float(thresh), list(lower), list(upper),
                                                         self.shape, self.x0, self.has_halo)
@@ -160,17 +189,20 @@ class SlabExtractor:
                 ops.append(dist.P2POp(dist.isend, send, self.rank - 1))
             if recv is not None:
                 ops.append(dist.P2POp(dist.irecv, recv, self.rank + 1))
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
+            return dist.batch_isend_irecv(ops) if ops else []
 
-        shift_to_prev(self.halo_send_buffer(), self.halo_recv_buffer())
+        # the halo plane travels while the interior planes are already being streamed
+        works = shift_to_prev(self.halo_send_buffer(), self.halo_recv_buffer())
+        self.phase_interior(thresh, lower, upper)
+        for w in works:
+            w.wait()
         nv, nf = self.phase_extract(thresh, lower, upper)
         mine = torch.tensor([nv, nf], dtype=torch.int64, device=self.grid.device)
         allc = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(allc, mine)
         counts = [(int(c[0]), int(c[1])) for c in torch.stack(allc).cpu()]
-        shift_to_prev(self.records_send_buffer(), self.records_recv_buffer())
+        for w in shift_to_prev(self.records_send_buffer(), self.records_recv_buffer()):
+            w.wait()
         return self.phase_faces(counts)
 
 
@@ -186,6 +218,8 @@ def extract_in_process(grid_full: torch.Tensor, world: int, thresh, lower=None, 
                          backend=backend_factory(r) if backend_factory else None) for r in range(world)]
     for e in exs:
         e.fill_local(lambda x0, x1: grid_full[x0:x1].to(device))
+    for e in exs:  # interior planes first (in the distributed run this overlaps the halo transfer)
+        e.phase_interior(thresh, lower, upper)
     for r in range(world - 1):  # phase A
         exs[r].halo_recv_buffer().copy_(exs[r + 1].halo_send_buffer())
     counts = [e.phase_extract(thresh, lower, upper) for e in exs]  # phase B

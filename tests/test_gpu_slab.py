@@ -17,13 +17,14 @@ def test_slabs_merge_to_the_whole_grid_mesh(gpu, world):
     from primitive3d_amd import capi
     from primitive3d_amd.fields import perlin_grid
     from primitive3d_amd.slab import SlabExtractor, slab_bounds
-    g = perlin_grid((37, 21, 150), period=12, seed=5).numpy()
+    g = perlin_grid((61, 21, 150), period=12, seed=5).numpy()   # 61 planes: world 2 gets slabs long enough to be split
     thresh, lower, upper = 0.02, [0.5, -1.0, 2.0], [3.0, 4.0, 9.0]
     full = torch.from_numpy(g).to(gpu)
     shape = g.shape
     exs = [SlabExtractor(shape, r, world, gpu) for r in range(world)]
     for e in exs:
         e.fill_local(lambda x0, x1: full[x0:x1])
+    splits = [e.phase_interior(thresh, lower, upper) for e in exs]  # interior planes before the halo arrives
     for r in range(world - 1):
         exs[r].halo_recv_buffer().copy_(exs[r + 1].halo_send_buffer())
     counts = [e.phase_extract(thresh, lower, upper) for e in exs]
