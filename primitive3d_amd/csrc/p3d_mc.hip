@@ -615,13 +615,11 @@ struct StageTimer {
     bool on;
     StageTimer(int stage_, hipStream_t st_) : stage(stage_), st(st_) {
         on = g_prof_mode == 2 || (g_prof_mode == 1 && (stage == ST_CLASSIFY || stage == ST_FUSED));
-        if (on) {
-            hipEventRecord(g_ev[stage][0], st);
-        }
+        if (on) (void)hipEventRecord(g_ev[stage][0], st);
     }
     ~StageTimer() {
         if (on) {
-            hipEventRecord(g_ev[stage][1], st);
+            (void)hipEventRecord(g_ev[stage][1], st);
             g_ev_used[stage] = true;
         }
     }
