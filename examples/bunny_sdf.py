@@ -1,11 +1,14 @@
 """The reference's examples/bunny_sdf.py on the MI355X build (input: the reference's bunny.npy, kept as
 tests/golden/bunny66.npy; known answer V=13282, F=26560)."""
 import os
+import sys
+from pathlib import Path
 
 import numpy as np
 import torch
 
-import prim3d
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))  # run from a source checkout
+import prim3d  # noqa: E402
 
 DENSITY_GRID = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "bunny66.npy"))
 print(f"DENSITY_GRID shape: ({DENSITY_GRID.shape[0]}, {DENSITY_GRID.shape[1]}, {DENSITY_GRID.shape[2]})")

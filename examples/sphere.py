@@ -2,10 +2,14 @@
 GPU extraction through `prim3d.marching_cubes`, PLY export, counts asserted against the reference's
 known answer (V=11766, F=23528; the reference compares with PyMCubes, which is used here only if
 installed)."""
+import sys
+from pathlib import Path
+
 import numpy as np
 import torch
 
-import prim3d
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))  # run from a source checkout
+import prim3d  # noqa: E402
 
 X, Y, Z = np.mgrid[:200, :200, :200]
 DENSITY_GRID = (X - 50) ** 2 + (Y - 50) ** 2 + (Z - 50) ** 2 - 25 ** 2
