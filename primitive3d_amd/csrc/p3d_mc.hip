@@ -28,6 +28,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <type_traits>
 
@@ -38,6 +39,8 @@ namespace {
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
+
+#include "tri_count_bitsliced.inc"
 
 __device__ const u64 g_tri_packed[256] = {P3D_TRI_TABLE_PACKED};
 __device__ const unsigned char g_tri_count[256] = {P3D_TRI_COUNT};
@@ -58,7 +61,9 @@ struct Ws {  // byte offsets into the workspace
 constexpr int kBlock = 256;
 constexpr int kHdrBytes = 8192;   // [0,256) totals/flags; [256,4352) 32 cursors, one 128-B line each; [4352,4608) region prefixes
 // header slots (u64)
-enum { H_V = 0, H_T = 1, H_FLAGS = 2, H_CURSORS = 32 /* u64 index */, H_PREFIX = 32 + 32 * 16 };
+enum { H_V = 0, H_T = 1, H_FLAGS = 2, H_RECFORM = 3 /* 1: rec[].x still region * 2^26 + slot */,
+       H_NOBBASE = 4 /* 1: faces were allocated on the fly, the per-tile bases were never built */, H_TCUR = 5,
+       H_CURSORS = 32 /* u64 index */, H_PREFIX = 32 + 32 * 16 };
 
 __host__ __device__ inline Dims make_dims(int64_t rx, int64_t ry, int64_t rz) {
     Dims d;
@@ -236,11 +241,28 @@ __global__ void __launch_bounds__(kBlock) k_unit_counts(const u64* __restrict__ 
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
 
+// Result mailbox: a 64-byte slot of pinned, host-coherent memory per call.  The kernel that learns a total stores it
+// there (payload first, then the call's sequence number with system-scope release), so the host can size the
+// output tensors while the remaining kernels are still running -- no copy engine, no stream synchronisation.
+//   slot[0] = seq (vertices valid)   slot[1] = V   slot[2] = flags     slot[3] = seq (faces valid)   slot[4] = F
+__device__ inline void mb_publish_v(u64* slot, u64 seq, u64 nv, u64 flags) {
+    if (!slot) return;
+    __hip_atomic_store(slot + 1, nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(slot + 2, flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(slot + 0, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ inline void mb_publish_f(u64* slot, u64 seq, u64 nf) {
+    if (!slot) return;
+    __hip_atomic_store(slot + 4, nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(slot + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // exclusive scan of block sums by ONE block of 1024 threads.  Thread t owns the contiguous run
 // [t*per, (t+1)*per), per a multiple of 4: 16-byte loads with no dependence between them, one block-wide scan of
 // the run totals, 16-byte stores.  The arrays are padded to 1024*per entries (make_ws).
 __global__ void __launch_bounds__(1024) k_scan_blocks(const u32* __restrict__ bsum, u32* __restrict__ bbase,
-                                                      int64_t nb, u64* __restrict__ total_out) {
+                                                      int64_t nb, u64* __restrict__ total_out, u64* mb, u64 seq,
+                                                      int faces) {
     __shared__ u64 s_w[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t per = ((nb + 1023) / 1024 + 3) / 4 * 4;
@@ -266,6 +288,11 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(const u32* __restrict__ bs
         if (w < wave) wbase += s_w[w];
         total += s_w[w];
     }
+    if (tid == 0) {  // the total first: the host is waiting for it
+        *total_out = total;
+        if (faces) mb_publish_f(mb, seq, total);
+        else mb_publish_v(mb, seq, total, 0ull);
+    }
     u64 run = wbase + inc - sum;
     uint4* dst = (uint4*)(bbase + i0);
     for (int64_t q = 0; q < per / 4; ++q) {
@@ -282,7 +309,6 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(const u32* __restrict__ bs
         run += (i + 3 < nb ? v.w : 0u);
         dst[q] = o;
     }
-    if (tid == 0) *total_out = total;
 }
 
 // per-unit vertex-id records from counts + scanned block bases
@@ -381,39 +407,218 @@ __global__ void __launch_bounds__(kBlock) k_emit_vertices(const T* __restrict__ 
 // Corner bit weights and edge numbering follow marching_cubes.cu:49-57 and :178-192.
 // ---------------------------------------------------------------------------------------------
 struct FaceArgs {
+    int xlate;  // rec[].x is region * 2^26 + slot (straight from the streaming kernel): make it dense on the fly
     int halo_last;
     int64_t vid_base, halo_vid_base;
     int64_t tpp;  // tiles per plane
+    u64* mb;      // FM_ALLOC: result mailbox slot (or null) and the call's sequence number
+    u64 seq;
 };
 
+#ifndef P3D_FABL  // dev-only ablation of k_faces: 1 no atomic, 2 no face stores, 3 count + allocation only
+#define P3D_FABL 0
+#endif
 constexpr int kCellCap = 2048;  // active cells expanded at a time (a 256-unit tile has up to 16384)
+enum { FM_EMIT = 1, FM_ALLOC = 2 };
+constexpr u64 kTileDone = 1ull << 40;  // FM_ALLOC packs the number of finished tiles above the face cursor
+
+// Block barrier + exclusive scan that order LDS traffic only (a __syncthreads() would also drain the face stores
+// still in flight) and scan on the DPP network.
+__device__ inline u32 block_excl_scan_lds(u32 v, u32* s_tmp /* >= 4 */, u32* total) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 inc = wave_prefix_sum(v);
+    lds_barrier();
+    if (lane == 63) s_tmp[wave] = inc;
+    lds_barrier();
+    u32 wbase = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        if (w < wave) wbase += s_tmp[w];
+    *total = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+    return wbase + inc - v;
+}
+__device__ inline void wave_lds_sync() {  // orders one wave's LDS traffic across its lanes (no block barrier)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Triangles per 256-unit tile (the tiles of k_faces), from the sign words alone.  Lane = unit: the 8 corner signs of
+// the unit's 64 cells are 8 words (the four column words and the same shifted by one voxel), and the triangle count
+// of all 64 cells comes out of a boolean network over those words (tri_count_bitsliced.inc: ~200 v_bitop3 per
+// unit) -- no table lookups, no cell list, no divergence.  This pass only feeds the scan that gives
+// k_faces<FM_EMIT> its tile bases.  Replaces the atomicAdd(counters + 1, ...) of marching_cubes.cu:60-65.
+__global__ void __launch_bounds__(kBlock) k_face_count(const u64* __restrict__ bits, Dims d, int64_t tpp,
+                                                       u32* __restrict__ bsum) {
+    __shared__ u32 s_tmp[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t b = blockIdx.x;
+    const int64_t x = b / tpp;
+    const int64_t p = (b - x * tpp) * kBlock + tid;
+    const int64_t y = p / d.ncz;
+    const int c = (int)(p - y * d.ncz);
+    const int64_t u = x * d.P + p;
+    const bool valid = (p < d.P) && (y + 1 < d.ry);
+    const bool more = c + 1 < d.ncz;
+    const int64_t uc[4] = {u, u + d.P, u + d.P + d.ncz, u + d.ncz};
+    u64 W[4] = {0, 0, 0, 0};
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) W[k] = bits[uc[k]];
+    }
+    const int first4 = (int)((W[0] & 1ull) | ((W[1] & 1ull) << 1) | ((W[2] & 1ull) << 2) | ((W[3] & 1ull) << 3));
+    int nbits = __shfl_down(first4, 1, 64);  // the next lane is the next chunk of the same row
+    if (lane == 63) {
+        nbits = 0;
+        if (valid && more) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nbits |= (int)(bits[uc[k] + 1] & 1ull) << k;
+        }
+    }
+    if (!more) nbits = 0;
+    u64 S[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) S[k] = (W[k] >> 1) | ((u64)((nbits >> k) & 1) << 63);
+    const u64 cells = valid ? zedge(d, c) : 0ull;  // cells of this unit that exist (inactive ones count 0 by themselves)
+    u32 n = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        u32 o0, o1, o2;
+        tri_count_bitsliced((u32)(W[0] >> (32 * h)), (u32)(W[1] >> (32 * h)), (u32)(W[2] >> (32 * h)),
+                            (u32)(W[3] >> (32 * h)), (u32)(S[0] >> (32 * h)), (u32)(S[1] >> (32 * h)),
+                            (u32)(S[2] >> (32 * h)), (u32)(S[3] >> (32 * h)), o0, o1, o2);
+        const u32 m = (u32)(cells >> (32 * h));
+        n += (u32)__popc(o0 & m) + 2u * (u32)__popc(o1 & m) + 4u * (u32)__popc(o2 & m);
+    }
+    n = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum(n), 63);
+    if (lane == 0) s_tmp[wave] = n;
+    __syncthreads();
+    if (tid == 0) bsum[b] = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+}
+
+// Compaction of the streaming kernel's 32 vertex regions, riding in the face kernel's launch: its first
+// `nblocks` blocks copy while the other blocks emit faces (a bandwidth-bound and a latency-bound job side by side,
+// one stream, no events).  Block j serves region j % 32, slice j / 32.  16-byte vectors aligned on the
+// destination; the source is read with 4-byte-aligned 16-byte loads.  Block 0 also finishes the header: V, the
+// overflow flag, the region prefixes and the record/tile-base form flags, and publishes V to the host.
+struct CompactArgs {
+    const float* scratch;  // null: nothing to copy (counting call), the header is still finished
+    float* verts;
+    int64_t capv;
+    u32 store_rows, region_rows;
+    int nblocks;           // multiple of kRegions (0: no compaction blocks in this launch)
+    int no_tile_bases;
+};
+typedef float F4U __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access at 4-byte alignment
+__device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr, u64* mb, u64 seq) {
+    __shared__ u64 s_cur[kRegions], s_pre[kRegions];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 64) {
+        const u64 cur = lane < kRegions ? hdr[H_CURSORS + lane * kCursorStride] : 0ull;
+        u64 inc = cur;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u64 tt = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += tt;
+        }
+        if (lane < kRegions) {
+            s_cur[lane] = cur;
+            s_pre[lane] = inc - cur;
+        }
+        if (blockIdx.x == 0) {
+            const u64 over = __ballot(cur > (u64)(c.scratch ? c.store_rows : c.region_rows));
+            if (lane < kRegions) hdr[H_PREFIX + lane] = inc - cur;
+            if (lane == kRegions - 1) {
+                hdr[H_V] = inc;
+                hdr[H_FLAGS] = over ? 1ull : 0ull;
+                hdr[H_RECFORM] = 1ull;
+                hdr[H_NOBBASE] = (u64)c.no_tile_bases;
+                mb_publish_v(mb, seq, inc, over ? 1ull : 0ull);
+            }
+        }
+    }
+    __syncthreads();
+    if (!c.scratch || c.capv <= 0) return;
+    const int r = blockIdx.x % kRegions, part = blockIdx.x / kRegions, nparts = c.nblocks / kRegions;
+    const int64_t rows = (int64_t)min(s_cur[r], (u64)c.store_rows);
+    const int64_t dst0 = (int64_t)s_pre[r] * 3;
+    const int64_t n = min(rows * 3, c.capv * 3 - dst0);  // floats to move (<= 0: nothing fits)
+    if (n <= 0) return;
+    const float* __restrict__ src = c.scratch + (size_t)r * c.store_rows * 3;
+    float* __restrict__ dst = c.verts + dst0;
+    const int64_t head = min(n, (int64_t)((4 - (dst0 & 3)) & 3));  // floats before the first 16-byte boundary of dst
+    const int64_t nvec = (n - head) >> 2;
+    const int64_t tail0 = head + nvec * 4;
+    if (part == 0 && tid < 8) {
+        if (tid < head) dst[tid] = src[tid];
+        if (tid >= 4 && tail0 + (tid - 4) < n) dst[tail0 + (tid - 4)] = src[tail0 + (tid - 4)];
+    }
+    const F4U* __restrict__ s4 = (const F4U*)(src + head);
+    float4* __restrict__ d4 = (float4*)(dst + head);
+    const int64_t stride = (int64_t)nparts * kBlock;
+    int64_t i = (int64_t)part * kBlock + tid;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {  // four loads in flight per lane
+        const F4U a0 = __builtin_nontemporal_load(s4 + i), a1 = __builtin_nontemporal_load(s4 + i + stride);
+        const F4U a2 = __builtin_nontemporal_load(s4 + i + 2 * stride), a3 = __builtin_nontemporal_load(s4 + i + 3 * stride);
+        d4[i] = make_float4(a0.x, a0.y, a0.z, a0.w);
+        d4[i + stride] = make_float4(a1.x, a1.y, a1.z, a1.w);
+        d4[i + 2 * stride] = make_float4(a2.x, a2.y, a2.z, a2.w);
+        d4[i + 3 * stride] = make_float4(a3.x, a3.y, a3.z, a3.w);
+    }
+    for (; i < nvec; i += stride) {
+        const F4U a0 = __builtin_nontemporal_load(s4 + i);
+        d4[i] = make_float4(a0.x, a0.y, a0.z, a0.w);
+    }
+}
 
 // Faces from sign words + vertex-id records.  One block = 256 units of one x plane.
-//   phase A (lane = unit)        : the 2x2 column words, their next-chunk bits, vertex-id records, active-cell word
-//   phase B (lane = unit)        : dense list of the tile's active cells (8 z-octant rounds if it does not fit)
-//   phase C (lane = active cell) : corner mask, triangle count; EMIT: the cell's 12 edge vertex ids -> LDS
-//   phase D (lane = TRIANGLE)    : three LDS lookups, 12 contiguous bytes stored per lane (fully coalesced)
+//   phase A (lane = unit, block)    : the 2x2 column words, their next-chunk bits, vertex-id records, active-cell word
+//   phase B (lane = unit, block)    : dense list of the tile's active cells (8 z-octant rounds if it does not fit)
+//   count   (lane = cell, per wave) : every wave takes a contiguous quarter of the list: corner masks -> LDS, triangles
+//   base                            : FM_EMIT   -> tile base from the scan over k_face_count's tile sums
+//                                                  (deterministic face order)
+//                                     FM_ALLOC  -> ONE returning atomic per tile on the face cursor hdr[H_T]
+//                                                  (face order = tile arrival order; unspecified in the reference too)
+//   phase C (lane = cell, per wave) : the cell's 12 edge vertex ids -> the wave's LDS slice
+//   phase D (lane = TRIANGLE)       : three LDS lookups, 12 contiguous bytes stored per lane (fully coalesced)
+// After the base is known the four waves never meet again: no block barrier sits between a face store and the next
+// batch.  With a.xlate the records are read in the streaming kernel's region form (region * 2^26 + slot) and made dense
+// on the fly from the 32 region cursors, so no pass over the records has to precede the faces.
 // Corner bit weights and edge numbering follow marching_cubes.cu:49-57 and :178-192.
-template <bool EMIT>
+template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, const uint2* __restrict__ rec, Dims d,
-                                                  FaceArgs a, const u32* __restrict__ bbase, u32* __restrict__ bsum,
-                                                  int32_t* __restrict__ faces, int64_t cap_faces) {
+                                                  FaceArgs a, CompactArgs cp, const u32* __restrict__ bbase,
+                                                  u64* __restrict__ hdr, int32_t* __restrict__ faces,
+                                                  int64_t cap_faces) {
+    if ((int)blockIdx.x < cp.nblocks) {  // the launch's first blocks move the vertices (uniform per block)
+        compact_block(cp, hdr, a.mb, a.seq);
+        return;
+    }
+    const bool XLATE = a.xlate != 0;
     __shared__ u64 s_tab[256];
     __shared__ unsigned char s_ntri[256];
-    __shared__ u64 s_w[kBlock][4];                    // W00,W10,W11,W01: bit k = sign of corner column j at z = 64c+k
-    __shared__ unsigned char s_nb[kBlock];            // bit j = sign of column j at the first voxel of the next chunk
-    __shared__ uint2 s_r[EMIT ? kBlock : 1][4];       // EMIT: vertex-id records of the 4 owner columns
-    __shared__ unsigned short s_cells[kCellCap];      // active cells of the current round: unit-in-tile << 6 | z
-    __shared__ unsigned char s_cmask[EMIT ? kBlock : 1];       // EMIT: corner mask of the batch's cells
-    __shared__ u32 s_ids[EMIT ? kBlock : 1][12];      // EMIT: vertex ids of the batch's cells' 12 edges
-    __shared__ unsigned short s_tri[EMIT ? kBlock * 5 : 1];    // EMIT: triangle -> cell-in-batch << 3 | slot
-    __shared__ u32 s_tmp[4];
+    __shared__ u64 s_w[4][kBlock];                       // W00,W10,W11,W01: bit k = sign of corner column j at z = 64c+k
+    __shared__ unsigned char s_nb[kBlock];               // bit j = sign of column j at the first voxel of the next chunk
+    __shared__ uint2 s_r[4][kBlock];                     // vertex-id records of the 4 owner columns
+    __shared__ unsigned short s_cells[kCellCap];         // active cells of the current round: unit-in-tile << 6 | z
+    __shared__ unsigned char s_mask[kCellCap];           // their corner masks
+    __shared__ u32 s_ids[4][12][64];                     // per wave: vertex ids of the batch's cells' 12 edges
+    __shared__ unsigned short s_tri[4][320];             // per wave: triangle -> cell-in-batch << 3 | slot
+    __shared__ unsigned char s_cm[4][64];                // per wave: corner mask of the batch's cells
+    __shared__ u32 s_pref[kRegions];
+    __shared__ u32 s_tmp[8];
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     s_tab[tid] = g_tri_packed[tid];
     s_ntri[tid] = g_tri_count[tid];
+    if (XLATE && wave == 0) {  // dense base of every region = exclusive prefix over the region cursors
+        const u32 cnt = lane < kRegions ? (u32)hdr[H_CURSORS + lane * kCursorStride] : 0u;
+        const u32 inc = wave_prefix_sum(cnt);
+        if (lane < kRegions) s_pref[lane] = inc - cnt;
+    }
+    auto dense = [&](u32 v) -> u32 { return XLATE ? (v & 0x3ffffffu) + s_pref[(v >> 26) & (kRegions - 1)] : v; };
 
-    const int64_t b = blockIdx.x;
+    const int64_t b = (int64_t)blockIdx.x - cp.nblocks;
     const int64_t x = b / a.tpp;
     const int64_t tile = b - x * a.tpp;
     const int64_t p = tile * kBlock + tid;
@@ -421,27 +626,41 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     const int c = (int)(p - y * d.ncz);
     const int64_t u = x * d.P + p;
     const bool valid = (p < d.P) && (y + 1 < d.ry);  // x+1 < rx by grid construction
+    const bool more = c + 1 < d.ncz;
 
     // phase A
-    u64 act_all = 0;
+    const int64_t uc[4] = {u, u + d.P, u + d.P + d.ncz, u + d.ncz};
+    u64 W[4] = {0, 0, 0, 0};
     if (valid) {
-        const int64_t uc[4] = {u, u + d.P, u + d.P + d.ncz, u + d.ncz};
-        u64 orr = 0, andd = ~0ull;
-        const bool more = c + 1 < d.ncz;
-        int nbits = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const u64 W = bits[uc[k]];
-            const u64 nb = more ? (bits[uc[k] + 1] & 1ull) : 0ull;
-            const u64 S = (W >> 1) | (nb << 63);
-            s_w[tid][k] = W;
-            nbits |= (int)nb << k;
-            if (EMIT) s_r[tid][k] = rec[uc[k]];  // only entries of units that own vertices are meaningful
-            orr |= W | S;
-            andd &= W & S;
+            W[k] = bits[uc[k]];
+            s_r[k][tid] = rec[uc[k]];  // only entries of units that own vertices are meaningful
+        }
+    }
+    // first bit of the next chunk of each column: the next lane holds it (same row), the wave's last lane loads it
+    const int first4 = (int)((W[0] & 1ull) | ((W[1] & 1ull) << 1) | ((W[2] & 1ull) << 2) | ((W[3] & 1ull) << 3));
+    int nbits = __shfl_down(first4, 1, 64);
+    if (lane == 63) {
+        nbits = 0;
+        if (valid && more) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nbits |= (int)(bits[uc[k] + 1] & 1ull) << k;
+        }
+    }
+    if (!more) nbits = 0;
+    u64 act_all = 0;
+    {
+        u64 orr = 0, andd = ~0ull;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u64 S = (W[k] >> 1) | ((u64)((nbits >> k) & 1) << 63);
+            s_w[k][tid] = W[k];
+            orr |= W[k] | S;
+            andd &= W[k] & S;
         }
         s_nb[tid] = (unsigned char)nbits;
-        act_all = orr & ~andd & zedge(d, c);
+        if (valid) act_all = orr & ~andd & zedge(d, c);
     }
 
     // corner mask of a cell: bits 0-3 = columns at z, bits 4-7 = the same columns at z+1
@@ -450,119 +669,150 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
         const int nbm = s_nb[t];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const u64 W = s_w[t][k];
-            lo |= (int)((W >> z) & 1ull) << k;
-            hi |= (z < 63 ? (int)((W >> (z + 1)) & 1ull) : ((nbm >> k) & 1)) << k;
+            const u64 Wk = s_w[k][t];
+            lo |= (int)((Wk >> z) & 1ull) << k;
+            hi |= (z < 63 ? (int)((Wk >> (z + 1)) & 1ull) : ((nbm >> k) & 1)) << k;
         }
         return lo | (hi << 4);
     };
 
     // the tile's cells are expanded into LDS in one round when they fit, else in eight z-octant rounds
     u32 na_tile;
-    (void)block_excl_scan((u32)popc64(act_all), s_tmp, &na_tile);
+    (void)block_excl_scan_lds((u32)popc64(act_all), s_tmp, &na_tile);
     const int rounds = na_tile <= (u32)kCellCap ? 1 : 8;
     const bool xhalo = a.halo_last && (x + 1 == d.rx - 1);  // columns 1,2 live in the imported plane
-    u32 run = EMIT ? bbase[b] : 0u;
-    u32 my_tris = 0;
+    const bool on_the_fly = MODE == FM_ALLOC || (MODE == FM_EMIT && hdr[H_NOBBASE] != 0ull);  // else: tile base from the scan
+    u64* const fcur = hdr + (MODE == FM_ALLOC ? H_T : H_TCUR);
+    int64_t run = (MODE == FM_EMIT && !on_the_fly) ? (int64_t)bbase[b] : 0;
 
     for (int rd = 0; rd < rounds; ++rd) {
         u64 act = rounds == 1 ? act_all : (act_all & (0xffull << (8 * rd)));
         // phase B
         u32 na_total;
-        u32 off = block_excl_scan((u32)popc64(act), s_tmp, &na_total);
+        u32 off = block_excl_scan_lds((u32)popc64(act), s_tmp, &na_total);
         while (act) {
             const int z = __ffsll((long long)act) - 1;
             act &= act - 1;
             s_cells[off++] = (unsigned short)((tid << 6) | z);
         }
-        __syncthreads();
+        lds_barrier();
 
-        if (!EMIT) {  // phase C, count only
-            for (u32 i = tid; i < na_total; i += kBlock) {
-                const int cell = s_cells[i];
-                my_tris += s_ntri[cell_mask(cell >> 6, cell & 63)];
-            }
-            continue;  // (next round's scan barriers order the reuse of s_cells)
+        // count: wave w owns cells [lo, hi)
+        const u32 per = (na_total + 3) >> 2;
+        const u32 lo = min((u32)wave * per, na_total), hi = min(lo + per, na_total);
+        u32 my = 0;
+        for (u32 i = lo + lane; i < hi; i += 64) {
+            const int cell = s_cells[i];
+            const int m = cell_mask(cell >> 6, cell & 63);
+            s_mask[i] = (unsigned char)m;
+            my += s_ntri[m];
         }
+        const u32 wsum = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum(my), 63);
+        if (lane == 0) s_tmp[4 + wave] = wsum;
+        lds_barrier();
+        u32 before = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const u32 v = s_tmp[4 + w];
+            tot += v;
+            if (w < wave) before += v;
+        }
+        if (on_the_fly) {
+#if P3D_FABL == 1
+            if (tid == 0) s_tmp[0] = (u32)b * 1270u;
+#else
+            // bits 40.. of the cursor count the tiles that made their last allocation: the last one knows F
+            if (tid == 0) {
+                const bool last = MODE == FM_ALLOC && rd == rounds - 1;
+                u64 old = 0;
+                if (tot || last) old = atomicAdd(fcur, (u64)tot | (last ? kTileDone : 0ull));
+                s_tmp[0] = (u32)old;
+                if (last && (old >> 40) + 1 == (u64)(gridDim.x - cp.nblocks)) mb_publish_f(a.mb, a.seq, (old & (kTileDone - 1)) + tot);
+            }
+#endif
+            lds_barrier();
+            run = (int64_t)s_tmp[0];
+        }
+        int64_t wrun = run + before;
+        if (!on_the_fly) run += tot;
+#if P3D_FABL == 3
+        continue;
+#endif
 
-        for (u32 i0 = 0; i0 < na_total; i0 += kBlock) {
+        for (u32 i0 = lo; i0 < hi; i0 += 64) {
             // phase C (lane = cell)
-            const u32 i = i0 + tid;
-            int mask = 0;
-            if (i < na_total) {
+            const u32 i = i0 + lane;
+            const int mask = i < hi ? (int)s_mask[i] : 0;
+            const u32 nt = s_ntri[mask];
+            if (nt) {
                 const int cell = s_cells[i];
                 const int t = cell >> 6, z = cell & 63;
-                mask = cell_mask(t, z);
-                if (s_ntri[mask]) {
-                    // crossing words of the 4 columns within this chunk
-                    const u64 W0 = s_w[t][0], W1 = s_w[t][1], W2 = s_w[t][2], W3 = s_w[t][3];
-                    const int nbm = s_nb[t];
-                    const u64 lowm = below(z);
-                    const u64 Cx0 = W0 ^ W1, Cx3 = W3 ^ W2;   // axis-0 edges of columns (x,y) and (x,y+1)
-                    const u64 Cy0 = W0 ^ W3, Cy1 = W1 ^ W2;   // axis-1 edges of columns (x,y) and (x+1,y)
-                    const uint2 r0 = s_r[t][0], r1 = s_r[t][1], r2 = s_r[t][2], r3 = s_r[t][3];
-                    const u32 b0 = a.vid_base, bh = xhalo ? (u32)a.halo_vid_base : (u32)a.vid_base;
-                    u32 id[12];
-                    // edges at z (ranks among the bits below z)
-                    id[0] = r0.x + b0 + (u32)popc64(Cx0 & lowm);
-                    id[2] = r3.x + b0 + (u32)popc64(Cx3 & lowm);
-                    id[3] = r0.x + b0 + (r0.y & 0xffffu) + (u32)popc64(Cy0 & lowm);
-                    id[1] = r1.x + bh + (r1.y & 0xffffu) + (u32)popc64(Cy1 & lowm);
-                    // edges at z+1: one more if the edge at z exists; the first voxel of the next chunk has rank 0
-                    if (z < 63) {
-                        id[4] = id[0] + (u32)((Cx0 >> z) & 1ull);
-                        id[6] = id[2] + (u32)((Cx3 >> z) & 1ull);
-                        id[7] = id[3] + (u32)((Cy0 >> z) & 1ull);
-                        id[5] = id[1] + (u32)((Cy1 >> z) & 1ull);
-                    } else {
-                        const int64_t pt = tile * kBlock + t;
-                        const bool in_tile = (t + 1 < kBlock);   // same row: c+1 < ncz is implied by a valid z+1
-                        const int64_t pu = x * d.P + pt;
-                        const uint2 n0 = in_tile ? s_r[t + 1][0] : rec[pu + 1];
-                        const uint2 n1 = in_tile ? s_r[t + 1][1] : rec[pu + d.P + 1];
-                        const uint2 n3 = in_tile ? s_r[t + 1][3] : rec[pu + d.ncz + 1];
-                        id[4] = n0.x + b0;
-                        id[6] = n3.x + b0;
-                        id[7] = n0.x + b0 + (n0.y & 0xffffu);
-                        id[5] = n1.x + bh + (n1.y & 0xffffu);
-                    }
-                    // axis-2 edges of the 4 columns (always inside this chunk)
-                    const u64 S0 = (W0 >> 1) | ((u64)(nbm & 1) << 63), S1 = (W1 >> 1) | ((u64)((nbm >> 1) & 1) << 63);
-                    const u64 S2 = (W2 >> 1) | ((u64)((nbm >> 2) & 1) << 63), S3 = (W3 >> 1) | ((u64)((nbm >> 3) & 1) << 63);
-                    id[8] = r0.x + b0 + (r0.y >> 16) + (u32)popc64((W0 ^ S0) & lowm);
-                    id[9] = r1.x + bh + (r1.y >> 16) + (u32)popc64((W1 ^ S1) & lowm);
-                    id[10] = r2.x + bh + (r2.y >> 16) + (u32)popc64((W2 ^ S2) & lowm);
-                    id[11] = r3.x + b0 + (r3.y >> 16) + (u32)popc64((W3 ^ S3) & lowm);
+                // crossing words of the 4 columns within this chunk
+                const u64 W0 = s_w[0][t], W1 = s_w[1][t], W2 = s_w[2][t], W3 = s_w[3][t];
+                const int nbm = s_nb[t];
+                const u64 lowm = below(z);
+                const u64 Cx0 = W0 ^ W1, Cx3 = W3 ^ W2;   // axis-0 edges of columns (x,y) and (x,y+1)
+                const u64 Cy0 = W0 ^ W3, Cy1 = W1 ^ W2;   // axis-1 edges of columns (x,y) and (x+1,y)
+                const uint2 r0 = s_r[0][t], r1 = s_r[1][t], r2 = s_r[2][t], r3 = s_r[3][t];
+                const u32 b0 = (u32)a.vid_base, bh = xhalo ? (u32)a.halo_vid_base : (u32)a.vid_base;
+                const u32 v0 = dense(r0.x) + b0, v1 = dense(r1.x) + bh, v2 = dense(r2.x) + bh, v3 = dense(r3.x) + b0;
+                u32 id[12];
+                // edges at z (ranks among the bits below z)
+                id[0] = v0 + (u32)popc64(Cx0 & lowm);
+                id[2] = v3 + (u32)popc64(Cx3 & lowm);
+                id[3] = v0 + (r0.y & 0xffffu) + (u32)popc64(Cy0 & lowm);
+                id[1] = v1 + (r1.y & 0xffffu) + (u32)popc64(Cy1 & lowm);
+                // edges at z+1: one more if the edge at z exists; the first voxel of the next chunk has rank 0
+                if (z < 63) {
+                    id[4] = id[0] + (u32)((Cx0 >> z) & 1ull);
+                    id[6] = id[2] + (u32)((Cx3 >> z) & 1ull);
+                    id[7] = id[3] + (u32)((Cy0 >> z) & 1ull);
+                    id[5] = id[1] + (u32)((Cy1 >> z) & 1ull);
+                } else {
+                    const int64_t pt = tile * kBlock + t;
+                    const bool in_tile = (t + 1 < kBlock);   // same row: c+1 < ncz is implied by a valid z+1
+                    const int64_t pu = x * d.P + pt;
+                    const uint2 n0 = in_tile ? s_r[0][t + 1] : rec[pu + 1];
+                    const uint2 n1 = in_tile ? s_r[1][t + 1] : rec[pu + d.P + 1];
+                    const uint2 n3 = in_tile ? s_r[3][t + 1] : rec[pu + d.ncz + 1];
+                    const u32 m0 = dense(n0.x) + b0;
+                    id[4] = m0;
+                    id[6] = dense(n3.x) + b0;
+                    id[7] = m0 + (n0.y & 0xffffu);
+                    id[5] = dense(n1.x) + bh + (n1.y & 0xffffu);
+                }
+                // axis-2 edges of the 4 columns (always inside this chunk)
+                const u64 S0 = (W0 >> 1) | ((u64)(nbm & 1) << 63), S1 = (W1 >> 1) | ((u64)((nbm >> 1) & 1) << 63);
+                const u64 S2 = (W2 >> 1) | ((u64)((nbm >> 2) & 1) << 63), S3 = (W3 >> 1) | ((u64)((nbm >> 3) & 1) << 63);
+                id[8] = v0 + (r0.y >> 16) + (u32)popc64((W0 ^ S0) & lowm);
+                id[9] = v1 + (r1.y >> 16) + (u32)popc64((W1 ^ S1) & lowm);
+                id[10] = v2 + (r2.y >> 16) + (u32)popc64((W2 ^ S2) & lowm);
+                id[11] = v3 + (r3.y >> 16) + (u32)popc64((W3 ^ S3) & lowm);
 #pragma unroll
-                    for (int e = 0; e < 12; ++e) s_ids[tid][e] = id[e];
-                }
+                for (int e = 0; e < 12; ++e) s_ids[wave][e][lane] = id[e];
             }
-            const u32 nt = s_ntri[mask];
-            u32 batch_total;
-            const u32 o = block_excl_scan(nt, s_tmp, &batch_total);  // (its barriers order the LDS reuse)
-            s_cmask[tid] = (unsigned char)mask;
-            for (u32 k = 0; k < nt; ++k) s_tri[o + k] = (unsigned short)((tid << 3) | k);
-            __syncthreads();
+            const u32 inc = wave_prefix_sum(nt);
+            const u32 o = inc - nt;
+            const u32 batch_total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+            s_cm[wave][lane] = (unsigned char)mask;
+            for (u32 k = 0; k < nt; ++k) s_tri[wave][o + k] = (unsigned short)((lane << 3) | k);
+            wave_lds_sync();
             // phase D (lane = triangle)
-            for (u32 tix = tid; tix < batch_total; tix += kBlock) {
-                const int ref = s_tri[tix];
+            for (u32 tix = lane; tix < batch_total; tix += 64) {
+                const int ref = s_tri[wave][tix];
                 const int ci = ref >> 3, k = ref & 7;
-                const u32 row3 = (u32)(s_tab[s_cmask[ci]] >> (12 * k));
-                const int64_t f = (int64_t)run + tix;
-                if (f < cap_faces) {
+                const u32 row3 = (u32)(s_tab[s_cm[wave][ci]] >> (12 * k));
+                const int64_t f = wrun + tix;
+                if (f < cap_faces && P3D_FABL != 2) {
                     int32_t* o3 = faces + f * 3;
-                    o3[0] = (int32_t)s_ids[ci][row3 & 15u];
-                    o3[1] = (int32_t)s_ids[ci][(row3 >> 4) & 15u];
-                    o3[2] = (int32_t)s_ids[ci][(row3 >> 8) & 15u];
+                    o3[0] = (int32_t)s_ids[wave][row3 & 15u][ci];
+                    o3[1] = (int32_t)s_ids[wave][(row3 >> 4) & 15u][ci];
+                    o3[2] = (int32_t)s_ids[wave][(row3 >> 8) & 15u][ci];
                 }
             }
-            run += batch_total;
-            __syncthreads();
+            wrun += batch_total;
+            wave_lds_sync();
         }
-    }
-    if (!EMIT) {
-        const u32 tile_tris = block_reduce_sum(my_tris, s_tmp);
-        if (tid == 0) bsum[b] = tile_tris;
     }
 }
 
@@ -602,7 +852,7 @@ int grid_for(int64_t work_items, int per_block, int64_t cap) {
 enum { ST_CLASSIFY = 0, ST_UNIT_COUNTS, ST_SCAN_V, ST_UNIT_RECORDS, ST_FACES_COUNT, ST_SCAN_F, ST_EMIT_VERTS,
        ST_EMIT_FACES, ST_FUSED, ST_FINALIZE, ST_N };
 const char* const k_stage_names[ST_N] = {"k_classify",    "k_unit_counts", "k_scan_blocks(v)", "k_unit_records",
-                                         "k_faces<count>", "k_scan_blocks(f)", "k_emit_vertices", "k_faces<emit>",
+                                         "k_face_count", "k_scan_blocks(f)", "k_emit_vertices", "k_faces<emit>",
                                          "k_fused", "k_finalize(prefix+fix_records+compact)"};
 int g_prof_mode = 0;  // 0 off, 1 dominant kernel only (k_classify), 2 every stage
 hipEvent_t g_ev[ST_N][2];
@@ -625,6 +875,101 @@ struct StageTimer {
     }
 };
 
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// ---- result mailbox (host side) ------------------------------------------------------------------
+// One ring of 64-byte slots in pinned host-coherent memory per device; every call that produces totals takes the
+// next sequence number, its kernels publish into slot seq % kMbSlots (mb_publish_*), and p3d_mc_read_counts polls that
+// slot.  The workspace pointer keys the pending call.  Anything unexpected (no pinned memory, slot recycled by 64
+// newer calls, time-out) falls back to the copy + synchronise path, which reads the same totals from the header.
+constexpr int kMbSlots = 64, kMbSlotWords = 8;
+struct Mailbox {
+    u64* host = nullptr;  // also valid as device pointer (hipHostMallocMapped, unified addressing)
+    u64* dev = nullptr;
+    u64 next_seq = 1;
+    bool failed = false;
+};
+struct PendingCall {
+    const void* ws = nullptr;
+    int dev = -1;
+    u64 seq = 0;
+};
+std::mutex g_mb_mu;
+Mailbox g_mb[64];
+PendingCall g_pending[kMbSlots];
+int g_pending_next = 0;
+
+// returns the device pointer of the slot and the sequence number; nullptr when the mailbox is unavailable
+u64* mailbox_open(const void* ws, u64* seq_out) {
+    static const bool disabled = env_int("P3D_NO_MAILBOX", 0) != 0;
+    *seq_out = 0;
+    if (disabled) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(g_mb_mu);
+    Mailbox& m = g_mb[dev];
+    if (m.failed) return nullptr;
+    if (!m.host) {
+        void* h = nullptr;
+        void* dptr = nullptr;
+        if (hipHostMalloc(&h, (size_t)kMbSlots * kMbSlotWords * 8,
+                          hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess ||
+            hipHostGetDevicePointer(&dptr, h, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            m.failed = true;
+            return nullptr;
+        }
+        memset(h, 0, (size_t)kMbSlots * kMbSlotWords * 8);
+        m.host = (u64*)h;
+        m.dev = (u64*)dptr;
+    }
+    const u64 seq = m.next_seq++;
+    for (auto& pc : g_pending)  // a workspace has one pending call at most
+        if (pc.ws == ws && pc.dev == dev) pc.ws = nullptr;
+    PendingCall& pc = g_pending[g_pending_next];
+    g_pending_next = (g_pending_next + 1) % kMbSlots;
+    pc.ws = ws;
+    pc.dev = dev;
+    pc.seq = seq;
+    *seq_out = seq;
+    return m.dev + (seq % kMbSlots) * kMbSlotWords;
+}
+
+// polls the slot of the pending call on `ws`; false = not pending / recycled / timed out (use the copy path)
+bool mailbox_wait(const void* ws, u64* nv, u64* nf, u64* flags) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    u64 seq = 0;
+    const volatile u64* slot = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_mb_mu);
+        for (auto& pc : g_pending)
+            if (pc.ws == ws && pc.dev == dev) {
+                seq = pc.seq;
+                pc.ws = nullptr;
+                slot = g_mb[dev].host + (seq % kMbSlots) * kMbSlotWords;
+                break;
+            }
+    }
+    if (!slot) return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spin = 0;; ++spin) {
+        const u64 sv = __atomic_load_n(&slot[0], __ATOMIC_ACQUIRE), sf = __atomic_load_n(&slot[3], __ATOMIC_ACQUIRE);
+        if (sv == seq && sf == seq) break;
+        if (sv > seq || sf > seq) return false;  // slot recycled by a newer call
+        if ((spin & 1023) == 1023 &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return false;
+        __builtin_ia32_pause();
+    }
+    *nv = slot[1];
+    *flags = slot[2];
+    *nf = slot[4];
+    return true;
+}
+
 template <typename T>
 int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3d_mc_slab* slab, char* ws,
                hipStream_t st) {
@@ -636,6 +981,9 @@ int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3
     u32 *bsv = (u32*)(ws + w.bsum_v), *bbv = (u32*)(ws + w.bbase_v);
     u32 *bsf = (u32*)(ws + w.bsum_f), *bbf = (u32*)(ws + w.bbase_f);
 
+    HIP_TRY(hipMemsetAsync(hdr + H_RECFORM, 0, 2 * sizeof(u64), st));  // dense ids, per-tile face bases
+    u64 seq = 0;
+    u64* mb = mailbox_open(ws, &seq);
     // classify: 64 units (16 KiB of fp32) per wave iteration; cap the grid and stride the rest
     const int64_t wave_iters = (d.U + 63) / 64;
     {
@@ -649,7 +997,7 @@ int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3
     }
     {
         StageTimer tm(ST_SCAN_V, st);
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, bsv, bbv, w.nb_v, hdr + H_V);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, bsv, bbv, w.nb_v, hdr + H_V, mb, seq, 0);
     }
     {
         StageTimer tm(ST_UNIT_RECORDS, st);
@@ -657,13 +1005,11 @@ int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3
     }
     if (w.nb_f > 0) {
         StageTimer tm(ST_FACES_COUNT, st);
-        FaceArgs a{halo, 0, 0, w.tpp};
-        hipLaunchKernelGGL(k_faces<false>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, bbf, bsf,
-                           (int32_t*)nullptr, (int64_t)0);
+        hipLaunchKernelGGL(k_face_count, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, d, w.tpp, bsf);
     }
     {
         StageTimer tm(ST_SCAN_F, st);
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, bsf, bbf, w.nb_f, hdr + H_T);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, bsf, bbf, w.nb_f, hdr + H_T, mb, seq, 1);
     }
     HIP_TRY(hipGetLastError());
     return P3D_OK;
@@ -676,7 +1022,11 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
     u64* bits = (u64*)(ws + w.bits);
     uint2* rec = (uint2*)(ws + w.rec);
     u32* cnt = (u32*)(ws + w.cnt);
-    u32 *bsf = (u32*)(ws + w.bsum_f), *bbf = (u32*)(ws + w.bbase_f);
+    u32* bbf = (u32*)(ws + w.bbase_f);
+    u64* hdr = (u64*)(ws + w.hdr);
+    // a one-pass call that allocated its faces on the fly leaves the records in region form: make them dense now
+    hipLaunchKernelGGL(k_fix_records, dim3((u32)w.nb_v), dim3(256), 0, st, rec, d.U, hdr, 1);
+    HIP_TRY(hipMemsetAsync(hdr + H_RECFORM, 0, sizeof(u64), st));
     if (capv > 0) {
         // per-unit crossing counts select the units to visit; recomputed here (12 us at 512^3) because the
         // fused streaming kernel does not materialise them
@@ -687,19 +1037,17 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
                            thresh, d, bits, cnt, rec, t, slab ? slab->x_origin : (int64_t)0, verts, capv, keys);
     }
     if (w.nb_f > 0 && capf > 0) {
+        HIP_TRY(hipMemsetAsync(hdr + H_TCUR, 0, sizeof(u64), st));  // face cursor, used if no per-tile bases exist
         StageTimer tm(ST_EMIT_FACES, st);
-        FaceArgs a{halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0, w.tpp};
-        hipLaunchKernelGGL(k_faces<true>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, bbf, bsf, faces,
-                           capf);
+        FaceArgs a{0, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0, w.tpp, nullptr, 0};
+        const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0};
+        hipLaunchKernelGGL(k_faces<FM_EMIT>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, none, bbf, hdr,
+                           faces, capf);
     }
     HIP_TRY(hipGetLastError());
     return P3D_OK;
 }
 
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
 
 template <typename T, int NC, int RY>
 void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xform& t, int64_t x_origin, u64* bits,
@@ -778,7 +1126,7 @@ Xform make_xform(const Dims& d, const float lower[3], const float upper[3], cons
 // side stream between two events so the two overlap.  One side stream + event pair per device, created lazily.
 struct SideStream {
     hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, fixed = nullptr, join = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
 };
 SideStream* side_stream_for_current_device() {
     static SideStream tab[64];
@@ -790,7 +1138,6 @@ SideStream* side_stream_for_current_device() {
     if (!s.stream) {
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.fixed, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) {
             s.stream = nullptr;
             return nullptr;
@@ -829,9 +1176,45 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         HIP_TRY(hipGetLastError());
         return P3D_OK;
     }
-    // After the streaming kernel two independent chains run side by side:
-    //   side stream : region prefix -> dense ids in rec[] (k_fix_records) -> compaction of the vertex regions
-    //   main stream : face count (needs only the sign words) -> scan -> [ids fixed] -> face emission
+    // What follows the streaming kernel:
+    //  * face buffer given, no halo plane (the single-GPU call): everything stays on the caller's stream.
+    //      few tiles  : k_faces<FM_ALLOC>                    counts, allocates (one atomic per tile) and emits
+    //      many tiles : k_face_count -> k_scan_blocks -> k_faces<FM_EMIT>   (a single cursor serves only ~88
+    //                   atomics/us, so tile bases come from a scan instead)
+    //    The first blocks of the k_faces launch copy the vertex regions to their dense place and finish the header
+    //    (V, flags, region prefixes); the records stay in region form and k_faces makes them dense on the fly.
+    //  * otherwise (slab with a halo plane, or counting only): the ids must become dense in rec[] because
+    //    p3d_mc_emit / the neighbour rank read them later.  Region prefix -> k_fix_records -> compaction run on a
+    //    side stream next to count -> scan.
+    const bool faces_here = w.nb_f > 0 && capf > 0 && !halo;
+    const bool onepass = faces_here && w.nb_f <= env_int("P3D_ONEPASS_MAX_TILES", 2048);
+    u64 seq = 0;
+    u64* mb = mailbox_open(ws, &seq);
+    FaceArgs a{1, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0, w.tpp, mb, seq};
+    if (faces_here) {
+        const bool copy = scratch && capv > 0;
+        CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows,
+                       copy ? std::max(1, env_int("P3D_COMPACT_BLOCKS", 512) / kRegions) * kRegions : kRegions,
+                       onepass ? 1 : 0};
+        if (!onepass) {
+            {
+                StageTimer tm(ST_FACES_COUNT, st);
+                hipLaunchKernelGGL(k_face_count, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, d, w.tpp, bsf);
+            }
+            StageTimer tm(ST_SCAN_F, st);
+            hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, bsf, bbf, w.nb_f, hdr + H_T, mb, seq, 1);
+        }
+        StageTimer tm(ST_EMIT_FACES, st);
+        if (onepass)
+            hipLaunchKernelGGL(k_faces<FM_ALLOC>, dim3((u32)(w.nb_f + cp.nblocks)), dim3(kBlock), 0, st, bits, rec, d, a,
+                               cp, bbf, hdr, faces, capf);
+        else
+            hipLaunchKernelGGL(k_faces<FM_EMIT>, dim3((u32)(w.nb_f + cp.nblocks)), dim3(kBlock), 0, st, bits, rec, d, a,
+                               cp, bbf, hdr, faces, capf);
+        HIP_TRY(hipGetLastError());
+        return P3D_OK;
+    }
+
     SideStream* side = env_int("P3D_NO_SIDE_STREAM", 0) ? nullptr : side_stream_for_current_device();
     hipStream_t fs = st;  // stream of the finalize chain
     if (side) {
@@ -842,30 +1225,20 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     {
         StageTimer tm(ST_FINALIZE, fs);
         hipLaunchKernelGGL(k_region_prefix, dim3(1), dim3(64), 0, fs, hdr, cursors, prefix,
-                           scratch ? store_rows : region_rows);
-        hipLaunchKernelGGL(k_fix_records, dim3((u32)w.nb_v), dim3(256), 0, fs, rec, d.U, prefix, region_rows);
+                           scratch ? store_rows : region_rows, 0, 0, mb, seq);
+        hipLaunchKernelGGL(k_fix_records, dim3((u32)w.nb_v), dim3(256), 0, fs, rec, d.U, hdr, 0);
     }
-    if (side) HIP_TRY(hipEventRecord(side->fixed, fs));
     if (scratch && capv > 0)
         hipLaunchKernelGGL(k_compact, dim3(64, kRegions), dim3(256), 0, fs, scratch, cursors, prefix, store_rows, verts,
                            capv);
     if (side) HIP_TRY(hipEventRecord(side->join, fs));
-
-    FaceArgs a{halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0, w.tpp};
     if (w.nb_f > 0) {
         StageTimer tm(ST_FACES_COUNT, st);
-        hipLaunchKernelGGL(k_faces<false>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, bbf, bsf,
-                           (int32_t*)nullptr, (int64_t)0);
+        hipLaunchKernelGGL(k_face_count, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, d, w.tpp, bsf);
     }
     {
         StageTimer tm(ST_SCAN_F, st);
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, bsf, bbf, w.nb_f, hdr + H_T);
-    }
-    if (side) HIP_TRY(hipStreamWaitEvent(st, side->fixed, 0));
-    if (w.nb_f > 0 && capf > 0 && !(slab && slab->halo_last_plane)) {
-        StageTimer tm(ST_EMIT_FACES, st);
-        hipLaunchKernelGGL(k_faces<true>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, bbf, bsf, faces,
-                           capf);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, bsf, bbf, w.nb_f, hdr + H_T, mb, seq, 1);
     }
     if (side) HIP_TRY(hipStreamWaitEvent(st, side->join, 0));  // the caller's stream owns both outputs again
     HIP_TRY(hipGetLastError());
@@ -906,8 +1279,11 @@ int p3d_mc_read_counts(const void* ws, int64_t* num_vertices, int64_t* num_faces
     if (!ws || !num_vertices || !num_faces) return fail(P3D_EINVAL, "null pointer%s");
     u64 h[3] = {0, 0, 0};
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemcpyAsync(h, ws, sizeof(h), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (!mailbox_wait(ws, &h[H_V], &h[H_T], &h[H_FLAGS])) {
+        HIP_TRY(hipMemcpyAsync(h, ws, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        h[H_T] &= kTileDone - 1;
+    }
     *num_vertices = (int64_t)h[H_V];
     *num_faces = (int64_t)h[H_T];
     if (scratch_overflow) *scratch_overflow = (int32_t)(h[H_FLAGS] & 1ull);

@@ -28,6 +28,11 @@ def vertex_keys_from_workspace(ws: np.ndarray, shape, nv: int, layout: dict, hal
     keys = np.full((nv,), -1, dtype=np.int64)
     lin = (np.arange(rx)[:, None, None] * ry + np.arange(ry)[None, :, None]) * rz + np.arange(zpad)[None, None, :]
     base = rec[..., 0].astype(np.int64)
+    hdr = ws[:8192].view(np.uint64)
+    if int(hdr[3]) == 1:  # H_RECFORM: the one-pass call left region * 2^26 + slot; dense base = slot + region prefix
+        prefix = hdr[32 + 32 * 16:32 + 32 * 16 + 32].astype(np.int64)  # H_PREFIX
+        region = np.minimum(base >> 26, 31)
+        base = (base & 0x3FFFFFF) + prefix[region]
     offy = (rec[..., 1] & 0xFFFF).astype(np.int64)
     offz = (rec[..., 1] >> 16).astype(np.int64)
     for axis, (cr, off) in enumerate(((cx, None), (cy, offy), (cz, offz))):

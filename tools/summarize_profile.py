@@ -7,7 +7,7 @@ import sys
 from collections import defaultdict
 
 d = sys.argv[1]
-ours = ("k_fused", "k_faces", "k_scan_blocks", "k_classify", "k_unit_counts", "k_unit_records", "k_emit_vertices", "k_region_prefix",
+ours = ("k_fused", "k_faces", "k_face_count", "k_scan_blocks", "k_classify", "k_unit_counts", "k_unit_records", "k_emit_vertices", "k_region_prefix",
         "k_fix_records", "k_compact")
 
 
