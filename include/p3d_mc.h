@@ -130,7 +130,8 @@ int p3d_mc_plane_records(void* ws, int64_t rx, int64_t ry, int64_t rz, int64_t p
  * Timer of prim3d/misc/utils.py:41-116).  mode 0 = off, 1 = hipEvents around the dominant kernel
  * only, 2 = around every stage.  Events are recorded on the stream passed to count/emit.
  * p3d_mc_profile_read synchronises those events and returns the per-stage durations (ms, -1 = not
- * recorded) of the most recent count/emit pair; it returns the number of stages (10; pass n >= 10). */
+ * recorded) of the most recent call; it returns the number of stages (11; pass n >= 11).  The dominant
+ * kernel's events ride on its own dispatch packet (hipExtLaunchKernel), so timing it does not perturb the stream. */
 int p3d_mc_profile_enable(int mode);
 int p3d_mc_profile_read(float* stage_ms, int n);
 const char* p3d_mc_profile_stage_name(int stage);

@@ -21,6 +21,7 @@
 //
 // No CUDA-compat shims, no dual paths: gfx950 only (wave64 hard-coded).
 #include <hip/hip_fp16.h>
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -31,6 +32,7 @@
 #include <chrono>
 #include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "../../include/p3d_mc.h"
 #include "tri_table_packed.inc"
@@ -59,7 +61,8 @@ struct Ws {  // byte offsets into the workspace
 };
 
 constexpr int kBlock = 256;
-constexpr int kHdrBytes = 8192;   // [0,256) totals/flags; [256,4352) 32 cursors, one 128-B line each; [4352,4608) region prefixes
+constexpr int kHdrBytes = 8192;   // [0,256) totals/flags; [4352,4608) region prefixes (the cursors themselves live in a
+                                  // library-owned ring, see cursor_block_for)
 // header slots (u64)
 enum { H_V = 0, H_T = 1, H_FLAGS = 2, H_RECFORM = 3 /* 1: rec[].x still region * 2^26 + slot */,
        H_NOBBASE = 4 /* 1: faces were allocated on the fly, the per-tile bases were never built */, H_TCUR = 5,
@@ -413,6 +416,9 @@ struct FaceArgs {
     int64_t tpp;  // tiles per plane
     u64* mb;      // FM_ALLOC: result mailbox slot (or null) and the call's sequence number
     u64 seq;
+    u64* cursors; // the call's cursor block: 32 vertex-region cursors, then the face cursor of FM_ALLOC
+    int xw;       // > 0: chunked face order (k_face_count_walk): bbase[] = offsets inside the chunk, chunk_sum[] = totals
+    const u32* chunk_sum;
 };
 
 #ifndef P3D_FABL  // dev-only ablation of k_faces: 1 no atomic, 2 no face stores, 3 count + allocation only
@@ -496,6 +502,88 @@ __global__ void __launch_bounds__(kBlock) k_face_count(const u64* __restrict__ b
     if (tid == 0) bsum[b] = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
 }
 
+// The same count for the one-pass call, organised so that NO scan kernel has to follow: a block owns a CHUNK = one
+// tile column over `xw` consecutive planes, walks it along x (every sign word is loaded once per chunk: plane x+1 of
+// one step is plane x of the next; all loads of a sub-batch of PB planes are issued together) and writes
+//   tile_off[x * tpp + tile] = triangles of the chunk's tiles before plane x      chunk_sum[chunk] = chunk total.
+// The face order is chunk-major (chunk = (x / xw) * tpp + tile); k_faces adds up the chunk sums before its own
+// chunk itself (a few hundred coalesced words per block).  The face order is unspecified in the reference.
+template <int PB>
+__global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restrict__ bits, Dims d, int64_t tpp, int xw,
+                                                            u32* __restrict__ chunk_sum, u32* __restrict__ tile_off) {
+    __shared__ u32 s_part[PB][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t chunk = blockIdx.x;
+    const int64_t xc = chunk / tpp, tile = chunk - xc * tpp;
+    const int64_t x_begin = xc * xw, x_end = min(x_begin + xw, d.rx - 1);  // cell layers [x_begin, x_end)
+    const int64_t p = tile * kBlock + tid;
+    const int64_t y = p / d.ncz;
+    const int c = (int)(p - y * d.ncz);
+    const bool valid = (p < d.P) && (y + 1 < d.ry);
+    const bool more = c + 1 < d.ncz;
+    const u64 cells = valid ? zedge(d, c) : 0ull;
+    u32 running = 0;  // thread 0: triangles of the chunk so far
+    for (int64_t xs = x_begin; xs < x_end; xs += PB) {
+        u64 Wp[PB + 1], Wq[PB + 1];  // columns (x', y) and (x', y+1) of this unit for x' = xs .. xs+PB
+        u32 first = 0, nbs = 0;
+        static_for<0, PB + 1>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int64_t u = min(xs + i, d.rx - 1) * d.P + p;
+            Wp[i] = valid ? bits[u] : 0ull;
+            Wq[i] = valid ? bits[u + d.ncz] : 0ull;
+        });
+        // first bit of the next chunk of both columns, all planes in one word: the next lane has them (same row);
+        // the wave's last lane loads them
+        static_for<0, PB + 1>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            first |= ((u32)(Wp[i] & 1ull) | ((u32)(Wq[i] & 1ull) << 1)) << (2 * i);
+        });
+        nbs = (u32)__shfl_down((int)first, 1, 64);
+        if (lane == 63) {
+            nbs = 0;
+            if (valid && more) {
+                static_for<0, PB + 1>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    const int64_t u = min(xs + i, d.rx - 1) * d.P + p;
+                    nbs |= ((u32)(bits[u + 1] & 1ull) | ((u32)(bits[u + d.ncz + 1] & 1ull) << 1)) << (2 * i);
+                });
+            }
+        }
+        if (!more) nbs = 0;
+        static_for<0, PB>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            u32 n = 0;
+            if (xs + i < x_end) {  // block-uniform
+                const u64 W0 = Wp[i], W1 = Wp[i + 1], W2 = Wq[i + 1], W3 = Wq[i];
+                const u64 S0 = (W0 >> 1) | ((u64)((nbs >> (2 * i)) & 1u) << 63);
+                const u64 S3 = (W3 >> 1) | ((u64)((nbs >> (2 * i + 1)) & 1u) << 63);
+                const u64 S1 = (W1 >> 1) | ((u64)((nbs >> (2 * i + 2)) & 1u) << 63);
+                const u64 S2 = (W2 >> 1) | ((u64)((nbs >> (2 * i + 3)) & 1u) << 63);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    u32 o0, o1, o2;
+                    tri_count_bitsliced((u32)(W0 >> (32 * h)), (u32)(W1 >> (32 * h)), (u32)(W2 >> (32 * h)),
+                                        (u32)(W3 >> (32 * h)), (u32)(S0 >> (32 * h)), (u32)(S1 >> (32 * h)),
+                                        (u32)(S2 >> (32 * h)), (u32)(S3 >> (32 * h)), o0, o1, o2);
+                    const u32 m = (u32)(cells >> (32 * h));
+                    n += (u32)__popc(o0 & m) + 2u * (u32)__popc(o1 & m) + 4u * (u32)__popc(o2 & m);
+                }
+            }
+            n = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum(n), 63);
+            if (lane == 0) s_part[i][wave] = n;
+        });
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 0; i < PB && xs + i < x_end; ++i) {
+                tile_off[(xs + i) * tpp + tile] = running;
+                running += s_part[i][0] + s_part[i][1] + s_part[i][2] + s_part[i][3];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) chunk_sum[chunk] = running;
+}
+
 // Compaction of the streaming kernel's 32 vertex regions, riding in the face kernel's launch: its first
 // `nblocks` blocks copy while the other blocks emit faces (a bandwidth-bound and a latency-bound job side by side,
 // one stream, no events).  Block j serves region j % 32, slice j / 32.  16-byte vectors aligned on the
@@ -508,13 +596,16 @@ struct CompactArgs {
     u32 store_rows, region_rows;
     int nblocks;           // multiple of kRegions (0: no compaction blocks in this launch)
     int no_tile_bases;
+    const u32* chunk_sum;  // chunked face order: block 0 adds the chunk sums up to F and tells the host
+    int nchunks;
+    const u64* cursors;    // the call's cursor block
 };
 typedef float F4U __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access at 4-byte alignment
 __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr, u64* mb, u64 seq) {
     __shared__ u64 s_cur[kRegions], s_pre[kRegions];
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid < 64) {
-        const u64 cur = lane < kRegions ? hdr[H_CURSORS + lane * kCursorStride] : 0ull;
+        const u64 cur = lane < kRegions ? c.cursors[lane * kCursorStride] : 0ull;
         u64 inc = cur;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -538,6 +629,20 @@ __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr
         }
     }
     __syncthreads();
+    if (blockIdx.x == 0 && c.chunk_sum) {
+        __shared__ u64 s_red[4];
+        u64 part_sum = 0;
+        for (int i = tid; i < c.nchunks; i += kBlock) part_sum += c.chunk_sum[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part_sum += __shfl_down(part_sum, o, 64);
+        if (lane == 0) s_red[tid >> 6] = part_sum;
+        __syncthreads();
+        if (tid == 0) {
+            const u64 nf = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+            hdr[H_T] = nf;
+            mb_publish_f(mb, seq, nf);
+        }
+    }
     if (!c.scratch || c.capv <= 0) return;
     const int r = blockIdx.x % kRegions, part = blockIdx.x / kRegions, nparts = c.nblocks / kRegions;
     const int64_t rows = (int64_t)min(s_cur[r], (u64)c.store_rows);
@@ -612,7 +717,7 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     s_tab[tid] = g_tri_packed[tid];
     s_ntri[tid] = g_tri_count[tid];
     if (XLATE && wave == 0) {  // dense base of every region = exclusive prefix over the region cursors
-        const u32 cnt = lane < kRegions ? (u32)hdr[H_CURSORS + lane * kCursorStride] : 0u;
+        const u32 cnt = lane < kRegions ? (u32)a.cursors[lane * kCursorStride] : 0u;
         const u32 inc = wave_prefix_sum(cnt);
         if (lane < kRegions) s_pref[lane] = inc - cnt;
     }
@@ -676,14 +781,26 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
         return lo | (hi << 4);
     };
 
+    // chunked face order: the chunks before this tile's chunk (summed by the whole block, collected below)
+    const bool chunked = MODE == FM_EMIT && a.xw > 0;
+    if (chunked) {
+        const int64_t mychunk = (x / a.xw) * a.tpp + tile;
+        u32 cs = 0;
+        for (int64_t i = tid; i < mychunk; i += kBlock) cs += a.chunk_sum[i];
+        cs = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum(cs), 63);
+        if (lane == 0) s_tmp[4 + wave] = cs;
+    }
     // the tile's cells are expanded into LDS in one round when they fit, else in eight z-octant rounds
     u32 na_tile;
     (void)block_excl_scan_lds((u32)popc64(act_all), s_tmp, &na_tile);
+    const u32 chunks_before = chunked ? s_tmp[4] + s_tmp[5] + s_tmp[6] + s_tmp[7] : 0u;
     const int rounds = na_tile <= (u32)kCellCap ? 1 : 8;
     const bool xhalo = a.halo_last && (x + 1 == d.rx - 1);  // columns 1,2 live in the imported plane
-    const bool on_the_fly = MODE == FM_ALLOC || (MODE == FM_EMIT && hdr[H_NOBBASE] != 0ull);  // else: tile base from the scan
-    u64* const fcur = hdr + (MODE == FM_ALLOC ? H_T : H_TCUR);
-    int64_t run = (MODE == FM_EMIT && !on_the_fly) ? (int64_t)bbase[b] : 0;
+    // base of the tile's faces: the scan's tile base / chunk sums + offset in the chunk / a cursor (FM_ALLOC, or a
+    // p3d_mc_emit after a one-pass call, which left no global tile bases behind)
+    const bool on_the_fly = MODE == FM_ALLOC || (MODE == FM_EMIT && !chunked && hdr[H_NOBBASE] != 0ull);
+    u64* const fcur = MODE == FM_ALLOC ? a.cursors + kRegions * kCursorStride : hdr + H_TCUR;
+    int64_t run = (MODE == FM_EMIT && !on_the_fly) ? (int64_t)chunks_before + (int64_t)bbase[b] : 0;
 
     for (int rd = 0; rd < rounds; ++rd) {
         u64 act = rounds == 1 ? act_all : (act_all & (0xffull << (8 * rd)));
@@ -727,7 +844,10 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
                 u64 old = 0;
                 if (tot || last) old = atomicAdd(fcur, (u64)tot | (last ? kTileDone : 0ull));
                 s_tmp[0] = (u32)old;
-                if (last && (old >> 40) + 1 == (u64)(gridDim.x - cp.nblocks)) mb_publish_f(a.mb, a.seq, (old & (kTileDone - 1)) + tot);
+                if (last && (old >> 40) + 1 == (u64)(gridDim.x - cp.nblocks)) {
+                    hdr[H_T] = (old & (kTileDone - 1)) + tot;
+                    mb_publish_f(a.mb, a.seq, (old & (kTileDone - 1)) + tot);
+                }
             }
 #endif
             lds_barrier();
@@ -850,10 +970,10 @@ int grid_for(int64_t work_items, int per_block, int64_t cap) {
 
 // ---- optional stage timing (bench/roofline): hipEvents recorded on the caller's stream ----------
 enum { ST_CLASSIFY = 0, ST_UNIT_COUNTS, ST_SCAN_V, ST_UNIT_RECORDS, ST_FACES_COUNT, ST_SCAN_F, ST_EMIT_VERTS,
-       ST_EMIT_FACES, ST_FUSED, ST_FINALIZE, ST_N };
+       ST_EMIT_FACES, ST_FUSED, ST_FINALIZE, ST_FUSED_INTERIOR, ST_N };
 const char* const k_stage_names[ST_N] = {"k_classify",    "k_unit_counts", "k_scan_blocks(v)", "k_unit_records",
                                          "k_face_count", "k_scan_blocks(f)", "k_emit_vertices", "k_faces<emit>",
-                                         "k_fused", "k_finalize(prefix+fix_records+compact)"};
+                                         "k_fused", "k_finalize(prefix+fix_records+compact)", "k_fused(interior part)"};
 int g_prof_mode = 0;  // 0 off, 1 dominant kernel only (k_classify), 2 every stage
 hipEvent_t g_ev[ST_N][2];
 bool g_ev_made = false;
@@ -878,6 +998,47 @@ struct StageTimer {
 int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
+}
+
+// ---- cursor blocks ---------------------------------------------------------------------------------
+// The streaming kernel's 32 output cursors (and the face cursor of FM_ALLOC) must be zero when a call starts.
+// Instead of a fill kernel per call the library owns, per (device, stream), a ring of kCursorRing cleared blocks:
+// call n uses block n % kCursorRing and its streaming kernel clears block (n + 1) % kCursorRing, whose last user ran
+// kCursorRing - 1 calls earlier on the same stream (stream order makes that safe).  A slab streamed in two parts
+// keeps its block for the second part.
+constexpr int kCursorRing = 4;
+struct CursorRing {
+    int dev = -1;
+    hipStream_t stream = nullptr;
+    u64* base = nullptr;
+    int cur = 0;
+};
+std::mutex g_ring_mu;
+std::vector<CursorRing> g_rings;
+
+// advance: take the next block (and return the one after it in *zero_next, to be cleared by this call's kernel)
+int cursor_block_for(hipStream_t st, bool advance, u64** block, u64** zero_next) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(g_ring_mu);
+    CursorRing* r = nullptr;
+    for (auto& e : g_rings)
+        if (e.dev == dev && e.stream == st) r = &e;
+    if (!r) {
+        CursorRing n;
+        n.dev = dev;
+        n.stream = st;
+        const size_t bytes = (size_t)kCursorRing * kCursorBlockWords * sizeof(u64);
+        HIP_TRY(hipMalloc((void**)&n.base, bytes));
+        HIP_TRY(hipMemsetAsync(n.base, 0, bytes, st));
+        n.cur = kCursorRing - 1;
+        g_rings.push_back(n);
+        r = &g_rings.back();
+    }
+    if (advance) r->cur = (r->cur + 1) % kCursorRing;
+    *block = r->base + (size_t)r->cur * kCursorBlockWords;
+    *zero_next = advance ? r->base + (size_t)((r->cur + 1) % kCursorRing) * kCursorBlockWords : nullptr;
+    return P3D_OK;
 }
 
 // ---- result mailbox (host side) ------------------------------------------------------------------
@@ -981,7 +1142,7 @@ int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3
     u32 *bsv = (u32*)(ws + w.bsum_v), *bbv = (u32*)(ws + w.bbase_v);
     u32 *bsf = (u32*)(ws + w.bsum_f), *bbf = (u32*)(ws + w.bbase_f);
 
-    HIP_TRY(hipMemsetAsync(hdr + H_RECFORM, 0, 2 * sizeof(u64), st));  // dense ids, per-tile face bases
+    HIP_TRY(hipMemsetAsync(hdr + H_FLAGS, 0, 3 * sizeof(u64), st));  // no overflow, dense ids, per-tile face bases
     u64 seq = 0;
     u64* mb = mailbox_open(ws, &seq);
     // classify: 64 units (16 KiB of fp32) per wave iteration; cap the grid and stride the rest
@@ -1039,8 +1200,8 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
     if (w.nb_f > 0 && capf > 0) {
         HIP_TRY(hipMemsetAsync(hdr + H_TCUR, 0, sizeof(u64), st));  // face cursor, used if no per-tile bases exist
         StageTimer tm(ST_EMIT_FACES, st);
-        FaceArgs a{0, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0, w.tpp, nullptr, 0};
-        const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0};
+        FaceArgs a{0, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0, w.tpp, nullptr, 0, nullptr, 0, nullptr};
+        const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0, nullptr};
         hipLaunchKernelGGL(k_faces<FM_EMIT>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, none, bbf, hdr,
                            faces, capf);
     }
@@ -1051,8 +1212,9 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
 
 template <typename T, int NC, int RY>
 void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xform& t, int64_t x_origin, u64* bits,
-                  uint2* rec, u64* cursors, float* scratch, u32 region_rows, u32 store_rows, int x_lo, int x_hi,
-                  hipStream_t st) {
+                  uint2* rec, u64* cursors, u64* zero_next, float* scratch, u32 region_rows, u32 store_rows, int x_lo,
+                  int x_hi,
+                  hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
     FusedGeom g;
     g.x_lo = x_lo;
     g.x_hi = x_hi;
@@ -1087,26 +1249,27 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
     const int64_t rest = nplanes - n_big * xt;
     g.nxt = (int)(n_big + (rest > 0 ? (rest + g.XT_tail - 1) / g.XT_tail : 0));
     const int64_t nblocks = per_slab * g.nxt;
-    hipLaunchKernelGGL((k_fused<T, NC, RY>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, grid, thresh, d, g, halo, t,
-                       x_origin, bits, rec, cursors, scratch, region_rows, store_rows);
+    // (the timing events, if any, ride on the dispatch packet itself: no extra barrier packets around the kernel)
+    if (ev0)
+        hipExtLaunchKernelGGL((k_fused<T, NC, RY>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, ev0, ev1, 0, grid, thresh,
+                              d, g, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows, store_rows);
+    else
+        hipLaunchKernelGGL((k_fused<T, NC, RY>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, grid, thresh, d, g, halo, t,
+                           x_origin, bits, rec, cursors, zero_next, scratch, region_rows, store_rows);
 }
 
 template <typename T>
 void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xform& t, int64_t x_origin, u64* bits,
-                    uint2* rec, u64* cursors, float* scratch, u32 region_rows, u32 store_rows, int x_lo, int x_hi,
-                    hipStream_t st) {
+                    uint2* rec, u64* cursors, u64* zero_next, float* scratch, u32 region_rows, u32 store_rows, int x_lo,
+                  int x_hi,
+                    hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
     // two tile geometries (both hold 32 unit words per wave-plane): long rows / short rows
-#ifdef P3D_EXP_GEOM47
     if (d.ncz >= 3)
-        launch_fused<T, 4, 7>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, scratch, region_rows, store_rows, st);
+        launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                              store_rows, x_lo, x_hi, ev0, ev1, st);
     else
-#endif
-    if (d.ncz >= 3)
-        launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, scratch, region_rows, store_rows,
-                              x_lo, x_hi, st);
-    else
-        launch_fused<T, 2, 15>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, scratch, region_rows, store_rows,
-                               x_lo, x_hi, st);
+        launch_fused<T, 2, 15>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                               store_rows, x_lo, x_hi, ev0, ev1, st);
 }
 
 Xform make_xform(const Dims& d, const float lower[3], const float upper[3], const int64_t full_res[3]) {
@@ -1155,7 +1318,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     u64* bits = (u64*)(ws + w.bits);
     uint2* rec = (uint2*)(ws + w.rec);
     u32 *bsf = (u32*)(ws + w.bsum_f), *bbf = (u32*)(ws + w.bbase_f);
-    u64 *cursors = hdr + H_CURSORS, *prefix = hdr + H_PREFIX;
+    u64* prefix = hdr + H_PREFIX;
     // Vertex ids handed out by the streaming kernel are region * 2^26 + slot (a fixed stride, so they stay
     // unambiguous even when a region outgrows its share of the scratch buffer); k_fix_records makes them dense.
     // Storage is store_rows rows per region; without a scratch buffer nothing is stored (pure count + ids).
@@ -1165,12 +1328,16 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     int x_lo = 0, x_hi = (int)d.rx;
     if (part == 1) x_hi = (int)slab->split_plane;
     if (part == 2) x_lo = (int)slab->split_plane;
-    if (part != 2) HIP_TRY(hipMemsetAsync(hdr, 0, kHdrBytes, st));
+    u64 *cursors = nullptr, *zero_next = nullptr;
+    if (int rc = cursor_block_for(st, part != 2, &cursors, &zero_next)) return rc;
     {
-        StageTimer tm(ST_FUSED, st);
+        const int stage = part == 1 ? ST_FUSED_INTERIOR : ST_FUSED;
+        const bool timed = g_prof_mode != 0;
+        if (timed) g_ev_used[stage] = true;
+        if (part == 0) g_ev_used[ST_FUSED_INTERIOR] = false;
         const int64_t xo = slab ? slab->x_origin : 0;
-        dispatch_fused<T>(grid, d, thresh, halo, t, xo, bits, rec, cursors, scratch, region_rows, store_rows, x_lo, x_hi,
-                          st);
+        dispatch_fused<T>(grid, d, thresh, halo, t, xo, bits, rec, cursors, zero_next, scratch, region_rows, store_rows, x_lo, x_hi,
+                          timed ? g_ev[stage][0] : nullptr, timed ? g_ev[stage][1] : nullptr, st);
     }
     if (part == 1) {  // the second part finalizes
         HIP_TRY(hipGetLastError());
@@ -1179,8 +1346,8 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     // What follows the streaming kernel:
     //  * face buffer given, no halo plane (the single-GPU call): everything stays on the caller's stream.
     //      few tiles  : k_faces<FM_ALLOC>                    counts, allocates (one atomic per tile) and emits
-    //      many tiles : k_face_count -> k_scan_blocks -> k_faces<FM_EMIT>   (a single cursor serves only ~88
-    //                   atomics/us, so tile bases come from a scan instead)
+    //      many tiles : k_face_count_walk -> k_faces<FM_EMIT>   (a single cursor serves only ~88 atomics/us, so the
+    //                   tile bases come from per-chunk counts instead; chunk-major face order)
     //    The first blocks of the k_faces launch copy the vertex regions to their dense place and finish the header
     //    (V, flags, region prefixes); the records stay in region form and k_faces makes them dense on the fly.
     //  * otherwise (slab with a halo plane, or counting only): the ids must become dense in rec[] because
@@ -1190,27 +1357,33 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     const bool onepass = faces_here && w.nb_f <= env_int("P3D_ONEPASS_MAX_TILES", 2048);
     u64 seq = 0;
     u64* mb = mailbox_open(ws, &seq);
-    FaceArgs a{1, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0, w.tpp, mb, seq};
+    FaceArgs a{1, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0, w.tpp, mb, seq, cursors, 0, nullptr};
     if (faces_here) {
         const bool copy = scratch && capv > 0;
+        // chunk = one tile column over xw planes (k_face_count_walk); at most 4096 chunks so that the per-tile sum over
+        // the preceding chunk totals stays a few KiB
+        int xw = 8;
+        while (((d.rx - 1 + xw - 1) / xw) * w.tpp > 4096) xw *= 2;
+        const int64_t nchunks = ((d.rx - 1 + xw - 1) / xw) * w.tpp;
         CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows,
-                       copy ? std::max(1, env_int("P3D_COMPACT_BLOCKS", 512) / kRegions) * kRegions : kRegions,
-                       onepass ? 1 : 0};
-        if (!onepass) {
-            {
-                StageTimer tm(ST_FACES_COUNT, st);
-                hipLaunchKernelGGL(k_face_count, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, d, w.tpp, bsf);
-            }
-            StageTimer tm(ST_SCAN_F, st);
-            hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, bsf, bbf, w.nb_f, hdr + H_T, mb, seq, 1);
-        }
-        StageTimer tm(ST_EMIT_FACES, st);
-        if (onepass)
+                       copy ? std::max(1, env_int("P3D_COMPACT_BLOCKS", 256) / kRegions) * kRegions : kRegions,
+                       1, onepass ? nullptr : bsf, (int)nchunks, cursors};
+        if (onepass) {
+            StageTimer tm(ST_EMIT_FACES, st);
             hipLaunchKernelGGL(k_faces<FM_ALLOC>, dim3((u32)(w.nb_f + cp.nblocks)), dim3(kBlock), 0, st, bits, rec, d, a,
                                cp, bbf, hdr, faces, capf);
-        else
+        } else {
+            {
+                StageTimer tm(ST_FACES_COUNT, st);
+                hipLaunchKernelGGL(k_face_count_walk<8>, dim3((u32)nchunks), dim3(kBlock), 0, st, bits, d, w.tpp, xw, bsf,
+                                   bbf);
+            }
+            a.xw = xw;
+            a.chunk_sum = bsf;
+            StageTimer tm(ST_EMIT_FACES, st);
             hipLaunchKernelGGL(k_faces<FM_EMIT>, dim3((u32)(w.nb_f + cp.nblocks)), dim3(kBlock), 0, st, bits, rec, d, a,
                                cp, bbf, hdr, faces, capf);
+        }
         HIP_TRY(hipGetLastError());
         return P3D_OK;
     }
@@ -1363,7 +1536,7 @@ int p3d_mc_profile_enable(int mode) {
 }
 
 int p3d_mc_profile_read(float* stage_ms, int n) {
-    if (!stage_ms || n < ST_N) return fail(P3D_EINVAL, "need room for 10 stages%s");
+    if (!stage_ms || n < ST_N) return fail(P3D_EINVAL, "need room for 11 stages%s");
     for (int i = 0; i < ST_N; ++i) {
         stage_ms[i] = -1.f;
         if (g_ev_made && g_ev_used[i]) {

@@ -89,19 +89,27 @@ def evaluate(lines, outs, xs):
 
 def main() -> int:
     ntri = load_counts()
-    net = Net()
-    outs = []
-    for o in range(3):
-        nodes = []
-        for sel in range(32):
-            imm = 0
-            for low in range(8):
-                m = low | (sel << 3)
-                imm |= ((ntri[m] >> o) & 1) << low
-            nodes.append(net.leaf(imm))
-        for lvl in range(5):  # select on x3 .. x7
-            nodes = [net.mux(f"x{3 + lvl}", nodes[2 * j + 1], nodes[2 * j]) for j in range(len(nodes) // 2)]
-        outs.append(nodes[0])
+    def build(cse_muxes):
+        net = Net()
+        net.cse_muxes = cse_muxes
+        outs = []
+        for o in range(3):
+            def node(level, sel):  # function of x0..x(2+level) with the higher variables fixed to `sel`
+                if level == 0:
+                    imm = 0
+                    for low in range(8):
+                        imm |= ((ntri[low | (sel << 3)] >> o) & 1) << low
+                    return net.leaf(imm)
+                hi = node(level - 1, (sel << 1) | 1)   # depth first: few values alive at any time
+                lo = node(level - 1, (sel << 1) | 0)
+                return net.mux(f"x{2 + level}", hi, lo)
+            # variable order: x7 is the top select, x3 the lowest; sel accumulates x7..x3 from the top
+            outs.append(node(5, 0))
+        return net, outs
+
+    def fix_sel_order(ntri_):
+        return ntri_
+    net, outs = build(True)
     # exhaustive check: bit position m of the inputs encodes mask m (256 masks = 8 words of 32)
     for base in range(0, 256, 32):
         xs = [sum(((((base + j) >> i) & 1) << j) for j in range(32)) for i in range(8)]
@@ -109,8 +117,25 @@ def main() -> int:
         for j in range(32):
             v = sum(((got[o] >> j) & 1) << o for o in range(3))
             assert v == ntri[base + j], (base + j, v, ntri[base + j])
-    body = "\n".join(net.lines)
+    # registers alive in emission order (depth first: a handful)
+    last_use = {}
+    for i, ln in enumerate(net.lines):
+        for t in re.findall(r"\bt\d+\b", ln.split("=", 1)[1]):
+            last_use[t] = i
+    for o_ in outs:
+        if isinstance(o_, str):
+            last_use[o_] = len(net.lines)
+    live, max_live = set(), 0
+    for i, ln in enumerate(net.lines):
+        live.add(re.match(r"\s*const u32 (\w+)", ln).group(1))
+        max_live = max(max_live, len(live))
+        live = {t for t in live if last_use.get(t, -1) > i}
+    lines = []
+    for i, ln in enumerate(net.lines):
+        lines.append(ln)
+    body = "\n".join(lines)
     ops = len(net.lines)
+    print("ops", ops, "max live temporaries", max_live)
     text = f"""// GENERATED by tools/gen_tri_count_bitsliced.py -- do not edit.
 // Triangle count of 32 cells at once: bit j of x0..x7 = corner sign i of cell j (corner order of the case mask);
 // bit j of o0/o1/o2 = bits 0/1/2 of that cell's triangle count.  {ops} word operations, verified against
