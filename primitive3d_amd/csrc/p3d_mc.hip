@@ -56,7 +56,9 @@ struct Dims {
 };
 
 struct Ws {  // byte offsets into the workspace
-    size_t hdr, bits, rec, cnt, bsum_v, bbase_v, bsum_f, bbase_f, total;
+    size_t hdr, bits, rec, cnt, bsum_v, bbase_v, chunk_sum, wave_off, total;
+    int64_t nchunks;  // face chunks (tile column x face_chunk_planes planes)
+    int xw;
     int64_t nb_v, nb_f, tpp;  // unit blocks, face blocks, face tiles per plane
 };
 
@@ -65,7 +67,6 @@ constexpr int kHdrBytes = 8192;   // [0,256) totals/flags; [4352,4608) region pr
                                   // library-owned ring, see cursor_block_for)
 // header slots (u64)
 enum { H_V = 0, H_T = 1, H_FLAGS = 2, H_RECFORM = 3 /* 1: rec[].x still region * 2^26 + slot */,
-       H_NOBBASE = 4 /* 1: faces were allocated on the fly, the per-tile bases were never built */, H_TCUR = 5,
        H_CURSORS = 32 /* u64 index */, H_PREFIX = 32 + 32 * 16 };
 
 __host__ __device__ inline Dims make_dims(int64_t rx, int64_t ry, int64_t rz) {
@@ -78,6 +79,14 @@ __host__ __device__ inline Dims make_dims(int64_t rx, int64_t ry, int64_t rz) {
     d.P = ry * d.ncz;
     d.U = rx * d.P;
     return d;
+}
+
+// face chunk = one tile column over this many planes: 8, doubled until there are at most 4096 chunks (every face tile
+// adds up the chunk totals before its own chunk: a few KiB of coalesced reads)
+inline int face_chunk_planes(int64_t rx, int64_t tpp) {
+    int xw = 8;
+    while (((rx - 1 + xw - 1) / xw) * tpp > 4096) xw *= 2;
+    return xw;
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -102,10 +111,12 @@ Ws make_ws(const Dims& d) {
     o = align_up(o + scan_pad(w.nb_v) * 4, 256);
     w.bbase_v = o;
     o = align_up(o + scan_pad(w.nb_v) * 4, 256);
-    w.bsum_f = o;
-    o = align_up(o + scan_pad(w.nb_f) * 4, 256);
-    w.bbase_f = o;
-    o = align_up(o + scan_pad(w.nb_f) * 4, 256);
+    w.xw = face_chunk_planes(d.rx, w.tpp);
+    w.nchunks = d.rx > 1 ? ((d.rx - 1 + w.xw - 1) / w.xw) * w.tpp : 0;
+    w.chunk_sum = o;   // triangles per chunk
+    o = align_up(o + (size_t)(w.nchunks + 1) * 4, 256);
+    w.wave_off = o;    // first face of every (tile, wave), relative to its chunk
+    o = align_up(o + (size_t)(w.nb_f + 1) * 4 * 4, 256);
     w.total = o;
     return w;
 }
@@ -402,115 +413,45 @@ __global__ void __launch_bounds__(kBlock) k_emit_vertices(const T* __restrict__ 
 #include "fused_stream.inc"
 
 // ---------------------------------------------------------------------------------------------
-// K4: faces from sign words + vertex-id records.  One block = 256 units of one x plane.
-//   phase A (lane = unit): load the 2x2 column words and their z+1 shifts, active-cell word
-//   phase B: expand active cells into a dense LDS list
-//   phase C (lane = active cell): 8-bit corner mask, triangle count; block sum
-//   EMIT: second sweep writes indices at bbase[block] + running offset
+// Faces.  Two kernels, both over TILES of 256 consecutive units of one x plane (4 waves x 64 units):
+//   k_face_count_walk : triangles per (tile, wave), by a boolean network over the sign words -> face offsets
+//   k_faces           : the triangles themselves, lane = active cell, then lane = triangle
+// Face order: chunk-major (chunk = one tile column over xw planes), then plane, tile, wave, cell.  The reference's
+// order is whatever its atomicAdd produced (marching_cubes.cu:200), so any order is in spec.
 // Corner bit weights and edge numbering follow marching_cubes.cu:49-57 and :178-192.
 // ---------------------------------------------------------------------------------------------
 struct FaceArgs {
     int xlate;  // rec[].x is region * 2^26 + slot (straight from the streaming kernel): make it dense on the fly
     int halo_last;
     int64_t vid_base, halo_vid_base;
-    int64_t tpp;  // tiles per plane
-    u64* mb;      // FM_ALLOC: result mailbox slot (or null) and the call's sequence number
+    int64_t tpp;           // tiles per plane
+    int xw;                // planes per chunk (face_chunk_planes)
+    const u32* chunk_sum;  // [nchunks] triangles per chunk
+    const u32* wave_off;   // [nb_f * 4] first face of (tile, wave) relative to its chunk
+    const u64* cursors;    // xlate: the call's 32 vertex-region cursors
+    u64* mb;               // result mailbox slot (or null) and the call's sequence number (compaction block 0 reports)
     u64 seq;
-    u64* cursors; // the call's cursor block: 32 vertex-region cursors, then the face cursor of FM_ALLOC
-    int xw;       // > 0: chunked face order (k_face_count_walk): bbase[] = offsets inside the chunk, chunk_sum[] = totals
-    const u32* chunk_sum;
 };
 
-#ifndef P3D_FABL  // dev-only ablation of k_faces: 1 no atomic, 2 no face stores, 3 count + allocation only
-#define P3D_FABL 0
-#endif
-constexpr int kCellCap = 2048;  // active cells expanded at a time (a 256-unit tile has up to 16384)
-enum { FM_EMIT = 1, FM_ALLOC = 2 };
-constexpr u64 kTileDone = 1ull << 40;  // FM_ALLOC packs the number of finished tiles above the face cursor
+constexpr int kWaveCells = 512;  // active cells a wave expands at a time (its 64 units have up to 4096)
 
-// Block barrier + exclusive scan that order LDS traffic only (a __syncthreads() would also drain the face stores
-// still in flight) and scan on the DPP network.
-__device__ inline u32 block_excl_scan_lds(u32 v, u32* s_tmp /* >= 4 */, u32* total) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u32 inc = wave_prefix_sum(v);
-    lds_barrier();
-    if (lane == 63) s_tmp[wave] = inc;
-    lds_barrier();
-    u32 wbase = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w)
-        if (w < wave) wbase += s_tmp[w];
-    *total = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
-    return wbase + inc - v;
-}
 __device__ inline void wave_lds_sync() {  // orders one wave's LDS traffic across its lanes (no block barrier)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Triangles per 256-unit tile (the tiles of k_faces), from the sign words alone.  Lane = unit: the 8 corner signs of
-// the unit's 64 cells are 8 words (the four column words and the same shifted by one voxel), and the triangle count
-// of all 64 cells comes out of a boolean network over those words (tri_count_bitsliced.inc: ~200 v_bitop3 per
-// unit) -- no table lookups, no cell list, no divergence.  This pass only feeds the scan that gives
-// k_faces<FM_EMIT> its tile bases.  Replaces the atomicAdd(counters + 1, ...) of marching_cubes.cu:60-65.
-__global__ void __launch_bounds__(kBlock) k_face_count(const u64* __restrict__ bits, Dims d, int64_t tpp,
-                                                       u32* __restrict__ bsum) {
-    __shared__ u32 s_tmp[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t b = blockIdx.x;
-    const int64_t x = b / tpp;
-    const int64_t p = (b - x * tpp) * kBlock + tid;
-    const int64_t y = p / d.ncz;
-    const int c = (int)(p - y * d.ncz);
-    const int64_t u = x * d.P + p;
-    const bool valid = (p < d.P) && (y + 1 < d.ry);
-    const bool more = c + 1 < d.ncz;
-    const int64_t uc[4] = {u, u + d.P, u + d.P + d.ncz, u + d.ncz};
-    u64 W[4] = {0, 0, 0, 0};
-    if (valid) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) W[k] = bits[uc[k]];
-    }
-    const int first4 = (int)((W[0] & 1ull) | ((W[1] & 1ull) << 1) | ((W[2] & 1ull) << 2) | ((W[3] & 1ull) << 3));
-    int nbits = __shfl_down(first4, 1, 64);  // the next lane is the next chunk of the same row
-    if (lane == 63) {
-        nbits = 0;
-        if (valid && more) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) nbits |= (int)(bits[uc[k] + 1] & 1ull) << k;
-        }
-    }
-    if (!more) nbits = 0;
-    u64 S[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) S[k] = (W[k] >> 1) | ((u64)((nbits >> k) & 1) << 63);
-    const u64 cells = valid ? zedge(d, c) : 0ull;  // cells of this unit that exist (inactive ones count 0 by themselves)
-    u32 n = 0;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        u32 o0, o1, o2;
-        tri_count_bitsliced((u32)(W[0] >> (32 * h)), (u32)(W[1] >> (32 * h)), (u32)(W[2] >> (32 * h)),
-                            (u32)(W[3] >> (32 * h)), (u32)(S[0] >> (32 * h)), (u32)(S[1] >> (32 * h)),
-                            (u32)(S[2] >> (32 * h)), (u32)(S[3] >> (32 * h)), o0, o1, o2);
-        const u32 m = (u32)(cells >> (32 * h));
-        n += (u32)__popc(o0 & m) + 2u * (u32)__popc(o1 & m) + 4u * (u32)__popc(o2 & m);
-    }
-    n = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum(n), 63);
-    if (lane == 0) s_tmp[wave] = n;
-    __syncthreads();
-    if (tid == 0) bsum[b] = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
-}
-
-// The same count for the one-pass call, organised so that NO scan kernel has to follow: a block owns a CHUNK = one
-// tile column over `xw` consecutive planes, walks it along x (every sign word is loaded once per chunk: plane x+1 of
-// one step is plane x of the next; all loads of a sub-batch of PB planes are issued together) and writes
-//   tile_off[x * tpp + tile] = triangles of the chunk's tiles before plane x      chunk_sum[chunk] = chunk total.
-// The face order is chunk-major (chunk = (x / xw) * tpp + tile); k_faces adds up the chunk sums before its own
-// chunk itself (a few hundred coalesced words per block).  The face order is unspecified in the reference.
+// Triangle counts.  A block owns a CHUNK = one tile column over `xw` consecutive planes and walks it along x: every
+// sign word is loaded once per chunk (plane x+1 of one step is plane x of the next; all loads of a sub-batch of PB
+// planes are issued together).  Lane = unit: the 8 corner signs of the unit's 64 cells are 8 words (the four column
+// words and the same shifted by one voxel), and the triangle count of all 64 cells comes out of a boolean network
+// over those words (tri_count_bitsliced.inc: ~200 v_bitop3 per unit) -- no table lookups, no cell list, no
+// divergence.  Output: wave_off[(x * tpp + tile) * 4 + w] = triangles of the chunk before wave w of that tile,
+// chunk_sum[chunk] = chunk total.  No scan follows: k_faces adds the chunk totals up itself.
+// Replaces the atomicAdd(counters + 1, ...) of marching_cubes.cu:60-65.
 template <int PB>
 __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restrict__ bits, Dims d, int64_t tpp, int xw,
-                                                            u32* __restrict__ chunk_sum, u32* __restrict__ tile_off) {
+                                                            u32* __restrict__ chunk_sum, u32* __restrict__ wave_off) {
     __shared__ u32 s_part[PB][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t chunk = blockIdx.x;
@@ -522,7 +463,7 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
     const bool valid = (p < d.P) && (y + 1 < d.ry);
     const bool more = c + 1 < d.ncz;
     const u64 cells = valid ? zedge(d, c) : 0ull;
-    u32 running = 0;  // thread 0: triangles of the chunk so far
+    u32 running = 0;  // threads 0..3: triangles of the chunk before this wave's share of the current plane
     for (int64_t xs = x_begin; xs < x_end; xs += PB) {
         u64 Wp[PB + 1], Wq[PB + 1];  // columns (x', y) and (x', y+1) of this unit for x' = xs .. xs+PB
         u32 first = 0, nbs = 0;
@@ -573,9 +514,11 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
             if (lane == 0) s_part[i][wave] = n;
         });
         __syncthreads();
-        if (tid == 0) {
+        if (tid < 4) {  // thread w keeps the running offset of wave w
             for (int i = 0; i < PB && xs + i < x_end; ++i) {
-                tile_off[(xs + i) * tpp + tile] = running;
+                u32 mine = running;
+                for (int w = 0; w < tid; ++w) mine += s_part[i][w];
+                wave_off[((xs + i) * tpp + tile) * 4 + tid] = mine;
                 running += s_part[i][0] + s_part[i][1] + s_part[i][2] + s_part[i][3];
             }
         }
@@ -584,19 +527,37 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
     if (tid == 0) chunk_sum[chunk] = running;
 }
 
+// F = sum of the chunk totals -> header + host mailbox (the counting call and the slab path; the one-pass call lets
+// block 0 of the k_faces launch do it)
+__global__ void __launch_bounds__(kBlock) k_face_total(const u32* __restrict__ chunk_sum, int nchunks,
+                                                       u64* __restrict__ hdr, u64* mb, u64 seq) {
+    __shared__ u64 s_red[4];
+    const int tid = threadIdx.x;
+    u64 part_sum = 0;
+    for (int i = tid; i < nchunks; i += kBlock) part_sum += chunk_sum[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part_sum += __shfl_down(part_sum, o, 64);
+    if ((tid & 63) == 0) s_red[tid >> 6] = part_sum;
+    __syncthreads();
+    if (tid == 0) {
+        const u64 nf = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        hdr[H_T] = nf;
+        mb_publish_f(mb, seq, nf);
+    }
+}
+
 // Compaction of the streaming kernel's 32 vertex regions, riding in the face kernel's launch: its first
-// `nblocks` blocks copy while the other blocks emit faces (a bandwidth-bound and a latency-bound job side by side,
+// `nblocks` blocks copy while the other blocks emit faces (a bandwidth-bound and an ALU-bound job side by side,
 // one stream, no events).  Block j serves region j % 32, slice j / 32.  16-byte vectors aligned on the
-// destination; the source is read with 4-byte-aligned 16-byte loads.  Block 0 also finishes the header: V, the
-// overflow flag, the region prefixes and the record/tile-base form flags, and publishes V to the host.
+// destination; the source is read with 4-byte-aligned 16-byte loads.  Block 0 also finishes the header: V, F, the
+// overflow flag, the region prefixes, the record form flag, and publishes V and F to the host.
 struct CompactArgs {
     const float* scratch;  // null: nothing to copy (counting call), the header is still finished
     float* verts;
     int64_t capv;
     u32 store_rows, region_rows;
     int nblocks;           // multiple of kRegions (0: no compaction blocks in this launch)
-    int no_tile_bases;
-    const u32* chunk_sum;  // chunked face order: block 0 adds the chunk sums up to F and tells the host
+    const u32* chunk_sum;  // block 0 adds the chunk sums up to F
     int nchunks;
     const u64* cursors;    // the call's cursor block
 };
@@ -623,13 +584,12 @@ __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr
                 hdr[H_V] = inc;
                 hdr[H_FLAGS] = over ? 1ull : 0ull;
                 hdr[H_RECFORM] = 1ull;
-                hdr[H_NOBBASE] = (u64)c.no_tile_bases;
                 mb_publish_v(mb, seq, inc, over ? 1ull : 0ull);
             }
         }
     }
     __syncthreads();
-    if (blockIdx.x == 0 && c.chunk_sum) {
+    if (blockIdx.x == 0) {
         __shared__ u64 s_red[4];
         u64 part_sum = 0;
         for (int i = tid; i < c.nchunks; i += kBlock) part_sum += c.chunk_sum[i];
@@ -676,43 +636,37 @@ __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr
     }
 }
 
-// Faces from sign words + vertex-id records.  One block = 256 units of one x plane.
-//   phase A (lane = unit, block)    : the 2x2 column words, their next-chunk bits, vertex-id records, active-cell word
-//   phase B (lane = unit, block)    : dense list of the tile's active cells (8 z-octant rounds if it does not fit)
-//   count   (lane = cell, per wave) : every wave takes a contiguous quarter of the list: corner masks -> LDS, triangles
-//   base                            : FM_EMIT   -> tile base from the scan over k_face_count's tile sums
-//                                                  (deterministic face order)
-//                                     FM_ALLOC  -> ONE returning atomic per tile on the face cursor hdr[H_T]
-//                                                  (face order = tile arrival order; unspecified in the reference too)
-//   phase C (lane = cell, per wave) : the cell's 12 edge vertex ids -> the wave's LDS slice
-//   phase D (lane = TRIANGLE)       : three LDS lookups, 12 contiguous bytes stored per lane (fully coalesced)
-// After the base is known the four waves never meet again: no block barrier sits between a face store and the next
-// batch.  With a.xlate the records are read in the streaming kernel's region form (region * 2^26 + slot) and made dense
-// on the fly from the 32 region cursors, so no pass over the records has to precede the faces.
-// Corner bit weights and edge numbering follow marching_cubes.cu:49-57 and :178-192.
-template <int MODE>
+// Faces from sign words + vertex-id records.  One block = one tile; after ONE block barrier (the staging below) its
+// four waves never meet again: wave w owns the cells of units 64w .. 64w+63 and knows where its faces start
+// (wave_off from k_face_count_walk + the chunk totals before its chunk).
+//   phase A (lane = unit, block) : the 2x2 column words, their next-chunk bits, vertex-id records -> LDS
+//   phase B (lane = unit, wave)  : dense list of the wave's active cells (8 z-octant rounds if it does not fit)
+//   phase C (lane = cell, wave)  : corner mask, the cell's 12 edge vertex ids -> the wave's LDS slice
+//   phase D (lane = TRIANGLE)    : three LDS lookups, 12 contiguous bytes stored per lane (fully coalesced)
+// No block barrier and no global load sits between a face store and the next batch (a barrier's or a load's
+// s_waitcnt vmcnt would wait for the stores in flight too).  With a.xlate the records are read in the streaming
+// kernel's region form (region * 2^26 + slot) and made dense on the fly from the 32 region cursors, so no pass over
+// the records has to precede the faces.
 __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, const uint2* __restrict__ rec, Dims d,
-                                                  FaceArgs a, CompactArgs cp, const u32* __restrict__ bbase,
-                                                  u64* __restrict__ hdr, int32_t* __restrict__ faces,
-                                                  int64_t cap_faces) {
+                                                  FaceArgs a, CompactArgs cp, u64* __restrict__ hdr,
+                                                  int32_t* __restrict__ faces, int64_t cap_faces) {
     if ((int)blockIdx.x < cp.nblocks) {  // the launch's first blocks move the vertices (uniform per block)
         compact_block(cp, hdr, a.mb, a.seq);
         return;
     }
-    const bool XLATE = a.xlate != 0;
     __shared__ u64 s_tab[256];
     __shared__ unsigned char s_ntri[256];
     __shared__ u64 s_w[4][kBlock];                       // W00,W10,W11,W01: bit k = sign of corner column j at z = 64c+k
     __shared__ unsigned char s_nb[kBlock];               // bit j = sign of column j at the first voxel of the next chunk
-    __shared__ uint2 s_r[4][kBlock];                     // vertex-id records of the 4 owner columns
-    __shared__ unsigned short s_cells[kCellCap];         // active cells of the current round: unit-in-tile << 6 | z
-    __shared__ unsigned char s_mask[kCellCap];           // their corner masks
+    __shared__ uint2 s_r[4][kBlock + 1];                 // vertex-id records of the 4 owner columns (+ the unit after the tile)
+    __shared__ unsigned short s_cells[4][kWaveCells];    // per wave: active cells of the round, unit-in-tile << 6 | z
     __shared__ u32 s_ids[4][12][64];                     // per wave: vertex ids of the batch's cells' 12 edges
     __shared__ unsigned short s_tri[4][320];             // per wave: triangle -> cell-in-batch << 3 | slot
     __shared__ unsigned char s_cm[4][64];                // per wave: corner mask of the batch's cells
     __shared__ u32 s_pref[kRegions];
-    __shared__ u32 s_tmp[8];
+    __shared__ u32 s_tmp[4];
 
+    const bool XLATE = a.xlate != 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     s_tab[tid] = g_tri_packed[tid];
     s_ntri[tid] = g_tri_count[tid];
@@ -743,6 +697,11 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
             s_r[k][tid] = rec[uc[k]];  // only entries of units that own vertices are meaningful
         }
     }
+    // the record of the unit that follows the tile's last one (its cells at z = 63 continue there) is staged too
+    if (tid == kBlock - 1 && valid && more) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_r[k][kBlock] = rec[uc[k] + 1];
+    }
     // first bit of the next chunk of each column: the next lane holds it (same row), the wave's last lane loads it
     const int first4 = (int)((W[0] & 1ull) | ((W[1] & 1ull) << 1) | ((W[2] & 1ull) << 2) | ((W[3] & 1ull) << 3));
     int nbits = __shfl_down(first4, 1, 64);
@@ -767,6 +726,16 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
         s_nb[tid] = (unsigned char)nbits;
         if (valid) act_all = orr & ~andd & zedge(d, c);
     }
+    // faces of the chunks before this tile's chunk (summed by the whole block)
+    {
+        const int64_t mychunk = (x / a.xw) * a.tpp + tile;
+        u32 cs = 0;
+        for (int64_t i = tid; i < mychunk; i += kBlock) cs += a.chunk_sum[i];
+        cs = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum(cs), 63);
+        if (lane == 0) s_tmp[wave] = cs;
+    }
+    __syncthreads();  // the only block barrier: staging done (no store is in flight yet)
+    int64_t wrun = (int64_t)(s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3]) + (int64_t)a.wave_off[b * 4 + wave];
 
     // corner mask of a cell: bits 0-3 = columns at z, bits 4-7 = the same columns at z+1
     auto cell_mask = [&](int t, int z) {
@@ -781,135 +750,77 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
         return lo | (hi << 4);
     };
 
-    // chunked face order: the chunks before this tile's chunk (summed by the whole block, collected below)
-    const bool chunked = MODE == FM_EMIT && a.xw > 0;
-    if (chunked) {
-        const int64_t mychunk = (x / a.xw) * a.tpp + tile;
-        u32 cs = 0;
-        for (int64_t i = tid; i < mychunk; i += kBlock) cs += a.chunk_sum[i];
-        cs = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum(cs), 63);
-        if (lane == 0) s_tmp[4 + wave] = cs;
-    }
-    // the tile's cells are expanded into LDS in one round when they fit, else in eight z-octant rounds
-    u32 na_tile;
-    (void)block_excl_scan_lds((u32)popc64(act_all), s_tmp, &na_tile);
-    const u32 chunks_before = chunked ? s_tmp[4] + s_tmp[5] + s_tmp[6] + s_tmp[7] : 0u;
-    const int rounds = na_tile <= (u32)kCellCap ? 1 : 8;
+    // the wave's cells are expanded into LDS in one round when they fit, else in eight z-octant rounds
+    const u32 nc_all = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum((u32)popc64(act_all)), 63);
+    const int rounds = nc_all <= (u32)kWaveCells ? 1 : 8;
     const bool xhalo = a.halo_last && (x + 1 == d.rx - 1);  // columns 1,2 live in the imported plane
-    // base of the tile's faces: the scan's tile base / chunk sums + offset in the chunk / a cursor (FM_ALLOC, or a
-    // p3d_mc_emit after a one-pass call, which left no global tile bases behind)
-    const bool on_the_fly = MODE == FM_ALLOC || (MODE == FM_EMIT && !chunked && hdr[H_NOBBASE] != 0ull);
-    u64* const fcur = MODE == FM_ALLOC ? a.cursors + kRegions * kCursorStride : hdr + H_TCUR;
-    int64_t run = (MODE == FM_EMIT && !on_the_fly) ? (int64_t)chunks_before + (int64_t)bbase[b] : 0;
+    const u32 b0 = (u32)a.vid_base, bh = xhalo ? (u32)a.halo_vid_base : (u32)a.vid_base;
+    unsigned short* const cells = s_cells[wave];
 
     for (int rd = 0; rd < rounds; ++rd) {
         u64 act = rounds == 1 ? act_all : (act_all & (0xffull << (8 * rd)));
         // phase B
-        u32 na_total;
-        u32 off = block_excl_scan_lds((u32)popc64(act), s_tmp, &na_total);
+        const u32 pc = (u32)popc64(act);
+        const u32 inc0 = wave_prefix_sum(pc);
+        const u32 na = (u32)__builtin_amdgcn_readlane((int)inc0, 63);
+        u32 off = inc0 - pc;
         while (act) {
             const int z = __ffsll((long long)act) - 1;
             act &= act - 1;
-            s_cells[off++] = (unsigned short)((tid << 6) | z);
+            cells[off++] = (unsigned short)((tid << 6) | z);
         }
-        lds_barrier();
+        wave_lds_sync();
 
-        // count: wave w owns cells [lo, hi)
-        const u32 per = (na_total + 3) >> 2;
-        const u32 lo = min((u32)wave * per, na_total), hi = min(lo + per, na_total);
-        u32 my = 0;
-        for (u32 i = lo + lane; i < hi; i += 64) {
-            const int cell = s_cells[i];
-            const int m = cell_mask(cell >> 6, cell & 63);
-            s_mask[i] = (unsigned char)m;
-            my += s_ntri[m];
-        }
-        const u32 wsum = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum(my), 63);
-        if (lane == 0) s_tmp[4 + wave] = wsum;
-        lds_barrier();
-        u32 before = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const u32 v = s_tmp[4 + w];
-            tot += v;
-            if (w < wave) before += v;
-        }
-        if (on_the_fly) {
-#if P3D_FABL == 1
-            if (tid == 0) s_tmp[0] = (u32)b * 1270u;
-#else
-            // bits 40.. of the cursor count the tiles that made their last allocation: the last one knows F
-            if (tid == 0) {
-                const bool last = MODE == FM_ALLOC && rd == rounds - 1;
-                u64 old = 0;
-                if (tot || last) old = atomicAdd(fcur, (u64)tot | (last ? kTileDone : 0ull));
-                s_tmp[0] = (u32)old;
-                if (last && (old >> 40) + 1 == (u64)(gridDim.x - cp.nblocks)) {
-                    hdr[H_T] = (old & (kTileDone - 1)) + tot;
-                    mb_publish_f(a.mb, a.seq, (old & (kTileDone - 1)) + tot);
-                }
-            }
-#endif
-            lds_barrier();
-            run = (int64_t)s_tmp[0];
-        }
-        int64_t wrun = run + before;
-        if (!on_the_fly) run += tot;
-#if P3D_FABL == 3
-        continue;
-#endif
-
-        for (u32 i0 = lo; i0 < hi; i0 += 64) {
+        for (u32 i0 = 0; i0 < na; i0 += 64) {
             // phase C (lane = cell)
             const u32 i = i0 + lane;
-            const int mask = i < hi ? (int)s_mask[i] : 0;
-            const u32 nt = s_ntri[mask];
-            if (nt) {
-                const int cell = s_cells[i];
+            int mask = 0;
+            u32 nt = 0;
+            if (i < na) {
+                const int cell = cells[i];
                 const int t = cell >> 6, z = cell & 63;
-                // crossing words of the 4 columns within this chunk
-                const u64 W0 = s_w[0][t], W1 = s_w[1][t], W2 = s_w[2][t], W3 = s_w[3][t];
-                const int nbm = s_nb[t];
-                const u64 lowm = below(z);
-                const u64 Cx0 = W0 ^ W1, Cx3 = W3 ^ W2;   // axis-0 edges of columns (x,y) and (x,y+1)
-                const u64 Cy0 = W0 ^ W3, Cy1 = W1 ^ W2;   // axis-1 edges of columns (x,y) and (x+1,y)
-                const uint2 r0 = s_r[0][t], r1 = s_r[1][t], r2 = s_r[2][t], r3 = s_r[3][t];
-                const u32 b0 = (u32)a.vid_base, bh = xhalo ? (u32)a.halo_vid_base : (u32)a.vid_base;
-                const u32 v0 = dense(r0.x) + b0, v1 = dense(r1.x) + bh, v2 = dense(r2.x) + bh, v3 = dense(r3.x) + b0;
-                u32 id[12];
-                // edges at z (ranks among the bits below z)
-                id[0] = v0 + (u32)popc64(Cx0 & lowm);
-                id[2] = v3 + (u32)popc64(Cx3 & lowm);
-                id[3] = v0 + (r0.y & 0xffffu) + (u32)popc64(Cy0 & lowm);
-                id[1] = v1 + (r1.y & 0xffffu) + (u32)popc64(Cy1 & lowm);
-                // edges at z+1: one more if the edge at z exists; the first voxel of the next chunk has rank 0
-                if (z < 63) {
-                    id[4] = id[0] + (u32)((Cx0 >> z) & 1ull);
-                    id[6] = id[2] + (u32)((Cx3 >> z) & 1ull);
-                    id[7] = id[3] + (u32)((Cy0 >> z) & 1ull);
-                    id[5] = id[1] + (u32)((Cy1 >> z) & 1ull);
-                } else {
-                    const int64_t pt = tile * kBlock + t;
-                    const bool in_tile = (t + 1 < kBlock);   // same row: c+1 < ncz is implied by a valid z+1
-                    const int64_t pu = x * d.P + pt;
-                    const uint2 n0 = in_tile ? s_r[0][t + 1] : rec[pu + 1];
-                    const uint2 n1 = in_tile ? s_r[1][t + 1] : rec[pu + d.P + 1];
-                    const uint2 n3 = in_tile ? s_r[3][t + 1] : rec[pu + d.ncz + 1];
-                    const u32 m0 = dense(n0.x) + b0;
-                    id[4] = m0;
-                    id[6] = dense(n3.x) + b0;
-                    id[7] = m0 + (n0.y & 0xffffu);
-                    id[5] = dense(n1.x) + bh + (n1.y & 0xffffu);
-                }
-                // axis-2 edges of the 4 columns (always inside this chunk)
-                const u64 S0 = (W0 >> 1) | ((u64)(nbm & 1) << 63), S1 = (W1 >> 1) | ((u64)((nbm >> 1) & 1) << 63);
-                const u64 S2 = (W2 >> 1) | ((u64)((nbm >> 2) & 1) << 63), S3 = (W3 >> 1) | ((u64)((nbm >> 3) & 1) << 63);
-                id[8] = v0 + (r0.y >> 16) + (u32)popc64((W0 ^ S0) & lowm);
-                id[9] = v1 + (r1.y >> 16) + (u32)popc64((W1 ^ S1) & lowm);
-                id[10] = v2 + (r2.y >> 16) + (u32)popc64((W2 ^ S2) & lowm);
-                id[11] = v3 + (r3.y >> 16) + (u32)popc64((W3 ^ S3) & lowm);
+                mask = cell_mask(t, z);
+                nt = s_ntri[mask];
+                if (nt) {
+                    // crossing words of the 4 columns within this chunk
+                    const u64 W0 = s_w[0][t], W1 = s_w[1][t], W2 = s_w[2][t], W3 = s_w[3][t];
+                    const int nbm = s_nb[t];
+                    const u64 lowm = below(z);
+                    const u64 Cx0 = W0 ^ W1, Cx3 = W3 ^ W2;   // axis-0 edges of columns (x,y) and (x,y+1)
+                    const u64 Cy0 = W0 ^ W3, Cy1 = W1 ^ W2;   // axis-1 edges of columns (x,y) and (x+1,y)
+                    const uint2 r0 = s_r[0][t], r1 = s_r[1][t], r2 = s_r[2][t], r3 = s_r[3][t];
+                    const u32 v0 = dense(r0.x) + b0, v1 = dense(r1.x) + bh, v2 = dense(r2.x) + bh, v3 = dense(r3.x) + b0;
+                    u32 id[12];
+                    // edges at z (ranks among the bits below z)
+                    id[0] = v0 + (u32)popc64(Cx0 & lowm);
+                    id[2] = v3 + (u32)popc64(Cx3 & lowm);
+                    id[3] = v0 + (r0.y & 0xffffu) + (u32)popc64(Cy0 & lowm);
+                    id[1] = v1 + (r1.y & 0xffffu) + (u32)popc64(Cy1 & lowm);
+                    // edges at z+1: one more if the edge at z exists; the first voxel of the next chunk has rank 0
+                    if (z < 63) {
+                        id[4] = id[0] + (u32)((Cx0 >> z) & 1ull);
+                        id[6] = id[2] + (u32)((Cx3 >> z) & 1ull);
+                        id[7] = id[3] + (u32)((Cy0 >> z) & 1ull);
+                        id[5] = id[1] + (u32)((Cy1 >> z) & 1ull);
+                    } else {
+                        // next chunk of the same row (c+1 < ncz is implied by a valid z+1): unit t+1, staged even for t = 255
+                        const uint2 n0 = s_r[0][t + 1], n1 = s_r[1][t + 1], n3 = s_r[3][t + 1];
+                        const u32 m0 = dense(n0.x) + b0;
+                        id[4] = m0;
+                        id[6] = dense(n3.x) + b0;
+                        id[7] = m0 + (n0.y & 0xffffu);
+                        id[5] = dense(n1.x) + bh + (n1.y & 0xffffu);
+                    }
+                    // axis-2 edges of the 4 columns (always inside this chunk)
+                    const u64 S0 = (W0 >> 1) | ((u64)(nbm & 1) << 63), S1 = (W1 >> 1) | ((u64)((nbm >> 1) & 1) << 63);
+                    const u64 S2 = (W2 >> 1) | ((u64)((nbm >> 2) & 1) << 63), S3 = (W3 >> 1) | ((u64)((nbm >> 3) & 1) << 63);
+                    id[8] = v0 + (r0.y >> 16) + (u32)popc64((W0 ^ S0) & lowm);
+                    id[9] = v1 + (r1.y >> 16) + (u32)popc64((W1 ^ S1) & lowm);
+                    id[10] = v2 + (r2.y >> 16) + (u32)popc64((W2 ^ S2) & lowm);
+                    id[11] = v3 + (r3.y >> 16) + (u32)popc64((W3 ^ S3) & lowm);
 #pragma unroll
-                for (int e = 0; e < 12; ++e) s_ids[wave][e][lane] = id[e];
+                    for (int e = 0; e < 12; ++e) s_ids[wave][e][lane] = id[e];
+                }
             }
             const u32 inc = wave_prefix_sum(nt);
             const u32 o = inc - nt;
@@ -923,7 +834,7 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
                 const int ci = ref >> 3, k = ref & 7;
                 const u32 row3 = (u32)(s_tab[s_cm[wave][ci]] >> (12 * k));
                 const int64_t f = wrun + tix;
-                if (f < cap_faces && P3D_FABL != 2) {
+                if (f < cap_faces) {
                     int32_t* o3 = faces + f * 3;
                     o3[0] = (int32_t)s_ids[wave][row3 & 15u][ci];
                     o3[1] = (int32_t)s_ids[wave][(row3 >> 4) & 15u][ci];
@@ -972,7 +883,7 @@ int grid_for(int64_t work_items, int per_block, int64_t cap) {
 enum { ST_CLASSIFY = 0, ST_UNIT_COUNTS, ST_SCAN_V, ST_UNIT_RECORDS, ST_FACES_COUNT, ST_SCAN_F, ST_EMIT_VERTS,
        ST_EMIT_FACES, ST_FUSED, ST_FINALIZE, ST_FUSED_INTERIOR, ST_N };
 const char* const k_stage_names[ST_N] = {"k_classify",    "k_unit_counts", "k_scan_blocks(v)", "k_unit_records",
-                                         "k_face_count", "k_scan_blocks(f)", "k_emit_vertices", "k_faces<emit>",
+                                         "k_face_count_walk", "k_face_total", "k_emit_vertices", "k_faces",
                                          "k_fused", "k_finalize(prefix+fix_records+compact)", "k_fused(interior part)"};
 int g_prof_mode = 0;  // 0 off, 1 dominant kernel only (k_classify), 2 every stage
 hipEvent_t g_ev[ST_N][2];
@@ -1001,7 +912,7 @@ int env_int(const char* name, int dflt) {
 }
 
 // ---- cursor blocks ---------------------------------------------------------------------------------
-// The streaming kernel's 32 output cursors (and the face cursor of FM_ALLOC) must be zero when a call starts.
+// The streaming kernel's 32 output cursors must be zero when a call starts.
 // Instead of a fill kernel per call the library owns, per (device, stream), a ring of kCursorRing cleared blocks:
 // call n uses block n % kCursorRing and its streaming kernel clears block (n + 1) % kCursorRing, whose last user ran
 // kCursorRing - 1 calls earlier on the same stream (stream order makes that safe).  A slab streamed in two parts
@@ -1140,9 +1051,9 @@ int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3
     uint2* rec = (uint2*)(ws + w.rec);
     u32* cnt = (u32*)(ws + w.cnt);
     u32 *bsv = (u32*)(ws + w.bsum_v), *bbv = (u32*)(ws + w.bbase_v);
-    u32 *bsf = (u32*)(ws + w.bsum_f), *bbf = (u32*)(ws + w.bbase_f);
+    u32 *csum = (u32*)(ws + w.chunk_sum), *woff = (u32*)(ws + w.wave_off);
 
-    HIP_TRY(hipMemsetAsync(hdr + H_FLAGS, 0, 3 * sizeof(u64), st));  // no overflow, dense ids, per-tile face bases
+    HIP_TRY(hipMemsetAsync(hdr + H_FLAGS, 0, 2 * sizeof(u64), st));  // no overflow, dense ids
     u64 seq = 0;
     u64* mb = mailbox_open(ws, &seq);
     // classify: 64 units (16 KiB of fp32) per wave iteration; cap the grid and stride the rest
@@ -1164,13 +1075,14 @@ int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3
         StageTimer tm(ST_UNIT_RECORDS, st);
         hipLaunchKernelGGL(k_unit_records, dim3((u32)w.nb_v), dim3(kBlock), 0, st, cnt, bbv, d, halo, rec);
     }
-    if (w.nb_f > 0) {
+    if (w.nchunks > 0) {
         StageTimer tm(ST_FACES_COUNT, st);
-        hipLaunchKernelGGL(k_face_count, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, d, w.tpp, bsf);
+        hipLaunchKernelGGL(k_face_count_walk<8>, dim3((u32)w.nchunks), dim3(kBlock), 0, st, bits, d, w.tpp, w.xw, csum,
+                           woff);
     }
     {
         StageTimer tm(ST_SCAN_F, st);
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, bsf, bbf, w.nb_f, hdr + H_T, mb, seq, 1);
+        hipLaunchKernelGGL(k_face_total, dim3(1), dim3(kBlock), 0, st, csum, (int)w.nchunks, hdr, mb, seq);
     }
     HIP_TRY(hipGetLastError());
     return P3D_OK;
@@ -1183,9 +1095,8 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
     u64* bits = (u64*)(ws + w.bits);
     uint2* rec = (uint2*)(ws + w.rec);
     u32* cnt = (u32*)(ws + w.cnt);
-    u32* bbf = (u32*)(ws + w.bbase_f);
     u64* hdr = (u64*)(ws + w.hdr);
-    // a one-pass call that allocated its faces on the fly leaves the records in region form: make them dense now
+    // a one-pass call leaves the records in region form: make them dense now
     hipLaunchKernelGGL(k_fix_records, dim3((u32)w.nb_v), dim3(256), 0, st, rec, d.U, hdr, 1);
     HIP_TRY(hipMemsetAsync(hdr + H_RECFORM, 0, sizeof(u64), st));
     if (capv > 0) {
@@ -1198,12 +1109,11 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
                            thresh, d, bits, cnt, rec, t, slab ? slab->x_origin : (int64_t)0, verts, capv, keys);
     }
     if (w.nb_f > 0 && capf > 0) {
-        HIP_TRY(hipMemsetAsync(hdr + H_TCUR, 0, sizeof(u64), st));  // face cursor, used if no per-tile bases exist
         StageTimer tm(ST_EMIT_FACES, st);
-        FaceArgs a{0, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0, w.tpp, nullptr, 0, nullptr, 0, nullptr};
-        const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0, nullptr};
-        hipLaunchKernelGGL(k_faces<FM_EMIT>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, none, bbf, hdr,
-                           faces, capf);
+        const FaceArgs a{0, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0, w.tpp, w.xw,
+                         (const u32*)(ws + w.chunk_sum), (const u32*)(ws + w.wave_off), nullptr, nullptr, 0};
+        const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr};
+        hipLaunchKernelGGL(k_faces, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, none, hdr, faces, capf);
     }
     HIP_TRY(hipGetLastError());
     return P3D_OK;
@@ -1317,7 +1227,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     u64* hdr = (u64*)(ws + w.hdr);
     u64* bits = (u64*)(ws + w.bits);
     uint2* rec = (uint2*)(ws + w.rec);
-    u32 *bsf = (u32*)(ws + w.bsum_f), *bbf = (u32*)(ws + w.bbase_f);
+    u32 *csum = (u32*)(ws + w.chunk_sum), *woff = (u32*)(ws + w.wave_off);
     u64* prefix = hdr + H_PREFIX;
     // Vertex ids handed out by the streaming kernel are region * 2^26 + slot (a fixed stride, so they stay
     // unambiguous even when a region outgrows its share of the scratch buffer); k_fix_records makes them dense.
@@ -1344,46 +1254,31 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         return P3D_OK;
     }
     // What follows the streaming kernel:
-    //  * face buffer given, no halo plane (the single-GPU call): everything stays on the caller's stream.
-    //      few tiles  : k_faces<FM_ALLOC>                    counts, allocates (one atomic per tile) and emits
-    //      many tiles : k_face_count_walk -> k_faces<FM_EMIT>   (a single cursor serves only ~88 atomics/us, so the
-    //                   tile bases come from per-chunk counts instead; chunk-major face order)
+    //  * face buffer given, no halo plane (the single-GPU call): two kernels on the caller's stream,
+    //      k_face_count_walk -> k_faces
     //    The first blocks of the k_faces launch copy the vertex regions to their dense place and finish the header
-    //    (V, flags, region prefixes); the records stay in region form and k_faces makes them dense on the fly.
+    //    (V, F, flags, region prefixes); the records stay in region form and k_faces makes them dense on the fly.
     //  * otherwise (slab with a halo plane, or counting only): the ids must become dense in rec[] because
     //    p3d_mc_emit / the neighbour rank read them later.  Region prefix -> k_fix_records -> compaction run on a
-    //    side stream next to count -> scan.
+    //    side stream next to k_face_count_walk -> k_face_total.
     const bool faces_here = w.nb_f > 0 && capf > 0 && !halo;
-    const bool onepass = faces_here && w.nb_f <= env_int("P3D_ONEPASS_MAX_TILES", 2048);
     u64 seq = 0;
     u64* mb = mailbox_open(ws, &seq);
-    FaceArgs a{1, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0, w.tpp, mb, seq, cursors, 0, nullptr};
+    if (w.nchunks > 0) {
+        StageTimer tm(ST_FACES_COUNT, st);
+        hipLaunchKernelGGL(k_face_count_walk<8>, dim3((u32)w.nchunks), dim3(kBlock), 0, st, bits, d, w.tpp, w.xw, csum,
+                           woff);
+    }
     if (faces_here) {
         const bool copy = scratch && capv > 0;
-        // chunk = one tile column over xw planes (k_face_count_walk); at most 4096 chunks so that the per-tile sum over
-        // the preceding chunk totals stays a few KiB
-        int xw = 8;
-        while (((d.rx - 1 + xw - 1) / xw) * w.tpp > 4096) xw *= 2;
-        const int64_t nchunks = ((d.rx - 1 + xw - 1) / xw) * w.tpp;
-        CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows,
-                       copy ? std::max(1, env_int("P3D_COMPACT_BLOCKS", 256) / kRegions) * kRegions : kRegions,
-                       1, onepass ? nullptr : bsf, (int)nchunks, cursors};
-        if (onepass) {
-            StageTimer tm(ST_EMIT_FACES, st);
-            hipLaunchKernelGGL(k_faces<FM_ALLOC>, dim3((u32)(w.nb_f + cp.nblocks)), dim3(kBlock), 0, st, bits, rec, d, a,
-                               cp, bbf, hdr, faces, capf);
-        } else {
-            {
-                StageTimer tm(ST_FACES_COUNT, st);
-                hipLaunchKernelGGL(k_face_count_walk<8>, dim3((u32)nchunks), dim3(kBlock), 0, st, bits, d, w.tpp, xw, bsf,
-                                   bbf);
-            }
-            a.xw = xw;
-            a.chunk_sum = bsf;
-            StageTimer tm(ST_EMIT_FACES, st);
-            hipLaunchKernelGGL(k_faces<FM_EMIT>, dim3((u32)(w.nb_f + cp.nblocks)), dim3(kBlock), 0, st, bits, rec, d, a,
-                               cp, bbf, hdr, faces, capf);
-        }
+        const FaceArgs a{1, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0, w.tpp, w.xw,
+                         csum, woff, cursors, mb, seq};
+        const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows,
+                             copy ? std::max(1, env_int("P3D_COMPACT_BLOCKS", 256) / kRegions) * kRegions : kRegions,
+                             csum, (int)w.nchunks, cursors};
+        StageTimer tm(ST_EMIT_FACES, st);
+        hipLaunchKernelGGL(k_faces, dim3((u32)(w.nb_f + cp.nblocks)), dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr,
+                           faces, capf);
         HIP_TRY(hipGetLastError());
         return P3D_OK;
     }
@@ -1398,20 +1293,16 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     {
         StageTimer tm(ST_FINALIZE, fs);
         hipLaunchKernelGGL(k_region_prefix, dim3(1), dim3(64), 0, fs, hdr, cursors, prefix,
-                           scratch ? store_rows : region_rows, 0, 0, mb, seq);
+                           scratch ? store_rows : region_rows, 0, mb, seq);
         hipLaunchKernelGGL(k_fix_records, dim3((u32)w.nb_v), dim3(256), 0, fs, rec, d.U, hdr, 0);
     }
     if (scratch && capv > 0)
         hipLaunchKernelGGL(k_compact, dim3(64, kRegions), dim3(256), 0, fs, scratch, cursors, prefix, store_rows, verts,
                            capv);
     if (side) HIP_TRY(hipEventRecord(side->join, fs));
-    if (w.nb_f > 0) {
-        StageTimer tm(ST_FACES_COUNT, st);
-        hipLaunchKernelGGL(k_face_count, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, d, w.tpp, bsf);
-    }
     {
         StageTimer tm(ST_SCAN_F, st);
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, bsf, bbf, w.nb_f, hdr + H_T, mb, seq, 1);
+        hipLaunchKernelGGL(k_face_total, dim3(1), dim3(kBlock), 0, st, csum, (int)w.nchunks, hdr, mb, seq);
     }
     if (side) HIP_TRY(hipStreamWaitEvent(st, side->join, 0));  // the caller's stream owns both outputs again
     HIP_TRY(hipGetLastError());
@@ -1455,7 +1346,6 @@ int p3d_mc_read_counts(const void* ws, int64_t* num_vertices, int64_t* num_faces
     if (!mailbox_wait(ws, &h[H_V], &h[H_T], &h[H_FLAGS])) {
         HIP_TRY(hipMemcpyAsync(h, ws, sizeof(h), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        h[H_T] &= kTileDone - 1;
     }
     *num_vertices = (int64_t)h[H_V];
     *num_faces = (int64_t)h[H_T];
