@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define P3D_MC_ABI_VERSION 3
+#define P3D_MC_ABI_VERSION 4
 
 /* dtype of the scalar field */
 #define P3D_F32 0
@@ -61,6 +61,12 @@ typedef struct p3d_mc_slab {
     int64_t halo_vertex_id_base; /* added to the imported records of the halo plane */
     int64_t x_origin;            /* global axis-0 index of local plane 0: vertex x = float(x_origin + x) + dt */
     int64_t split_plane;         /* see `part` */
+    const int64_t* rank_counts;  /* optional DEVICE pointer to the all-gathered {vertices, faces} pairs of all ranks
+                                    ([world][2] int64).  When set, the face kernel derives the two bases itself
+                                    (vertex_id_base = sum of the vertex counts of ranks < rank, halo base = that +
+                                    this rank's count) and ignores the two fields above: the host never waits
+                                    for the other ranks' counts, the all-gather result stays on the device. */
+    int32_t rank;                /* index of this rank in rank_counts */
 } p3d_mc_slab;
 
 /* Bytes of device scratch p3d_mc_count / p3d_mc_emit need for an [rx,ry,rz] grid.

@@ -19,7 +19,8 @@ SYMBOLS = ("p3d_mc_abi_version", "p3d_last_error", "p3d_mc_workspace_bytes", "p3
 class Slab(ctypes.Structure):
     """p3d_mc_slab (include/p3d_mc.h)."""
     _fields_ = [("halo_last_plane", c_int32), ("part", c_int32), ("vertex_id_base", c_int64),
-                ("halo_vertex_id_base", c_int64), ("x_origin", c_int64), ("split_plane", c_int64)]
+                ("halo_vertex_id_base", c_int64), ("x_origin", c_int64), ("split_plane", c_int64),
+                ("rank_counts", c_void_p), ("rank", c_int32)]
 
 
 class P3DError(RuntimeError):

@@ -424,6 +424,8 @@ struct FaceArgs {
     int xlate;  // rec[].x is region * 2^26 + slot (straight from the streaming kernel): make it dense on the fly
     int halo_last;
     int64_t vid_base, halo_vid_base;
+    const int64_t* rank_counts;  // optional: all-gathered {V, F} of all ranks on the device; bases are derived from it
+    int rank;
     int64_t tpp;           // tiles per plane
     int xw;                // planes per chunk (face_chunk_planes)
     const u32* chunk_sum;  // [nchunks] triangles per chunk
@@ -754,7 +756,14 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     const u32 nc_all = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum((u32)popc64(act_all)), 63);
     const int rounds = nc_all <= (u32)kWaveCells ? 1 : 8;
     const bool xhalo = a.halo_last && (x + 1 == d.rx - 1);  // columns 1,2 live in the imported plane
-    const u32 b0 = (u32)a.vid_base, bh = xhalo ? (u32)a.halo_vid_base : (u32)a.vid_base;
+    u32 b0 = (u32)a.vid_base, bhalo = (u32)a.halo_vid_base;
+    if (a.rank_counts) {  // uniform: a handful of scalar loads
+        int64_t acc = 0;
+        for (int r = 0; r < a.rank; ++r) acc += a.rank_counts[2 * r];
+        b0 = (u32)acc;
+        bhalo = (u32)(acc + a.rank_counts[2 * a.rank]);
+    }
+    const u32 bh = xhalo ? bhalo : b0;
     unsigned short* const cells = s_cells[wave];
 
     for (int rd = 0; rd < rounds; ++rd) {
@@ -1110,7 +1119,8 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
     }
     if (w.nb_f > 0 && capf > 0) {
         StageTimer tm(ST_EMIT_FACES, st);
-        const FaceArgs a{0, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0, w.tpp, w.xw,
+        const FaceArgs a{0, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
+                         slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw,
                          (const u32*)(ws + w.chunk_sum), (const u32*)(ws + w.wave_off), nullptr, nullptr, 0};
         const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr};
         hipLaunchKernelGGL(k_faces, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, none, hdr, faces, capf);
@@ -1271,7 +1281,8 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     }
     if (faces_here) {
         const bool copy = scratch && capv > 0;
-        const FaceArgs a{1, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0, w.tpp, w.xw,
+        const FaceArgs a{1, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
+                         slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw,
                          csum, woff, cursors, mb, seq};
         const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows,
                              copy ? std::max(1, env_int("P3D_COMPACT_BLOCKS", 256) / kRegions) * kRegions : kRegions,

@@ -17,7 +17,6 @@ all-gather of the per-rank counts.  No other collective touches the data path.
 The compute backend is pluggable so the orchestration can be tested without a GPU: `HipBackend`
 drives the C ABI (include/p3d_mc.h); tests inject a CPU stand-in built on the oracle.
 """
-from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -57,7 +56,8 @@ class HipBackend:
         capv = self._cap if self._cap is not None else max(4096, rx * ry * rz // 16)
         self._verts = torch.empty((capv, 3), dtype=torch.float32, device=self.device)
         self._scratch = torch.empty((c.scratch_rows_for(capv), 3), dtype=torch.float32, device=self.device)
-        self._mk = lambda part=0, split=0, vb=0, hb=0: c.Slab(1 if halo else 0, part, vb, hb, x_origin, split)
+        self._mk = lambda part=0, split=0, vb=0, hb=0, rc=None, rank=0: c.Slab(
+            1 if halo else 0, part, vb, hb, x_origin, split, rc.data_ptr() if rc is not None else None, rank)
 
     def begin_interior(self, grid, thresh, lower, upper, full_res, x_origin, halo, split):
         """Stream planes [0, split): they do not touch the halo plane, so this can run while it is in flight."""
@@ -104,16 +104,40 @@ class HipBackend:
         self.capi.emit(grid, thresh, lower, upper, ws, None, faces, slab=slab, full_res=full_res)
         return faces
 
+    def faces_from_rank_counts(self, rank_counts, rank):
+        """Same, with the id bases derived ON THE DEVICE from the all-gathered [world, 2] int64 counts: the host does
+        not wait for the other ranks (include/p3d_mc.h: p3d_mc_slab.rank_counts)."""
+        grid, thresh, lower, upper, full_res, ws, nf = self._state
+        slab = self._mk(0, 0, 0, 0, rank_counts, rank)
+        faces = torch.empty((nf, 3), dtype=torch.int32, device=self.device)
+        self.capi.emit(grid, thresh, lower, upper, ws, None, faces, slab=slab, full_res=full_res)
+        return faces
+
 
 # ---------------------------------------------------------------------------------------------
 # orchestration
 # ---------------------------------------------------------------------------------------------
-@dataclass
 class SlabResult:
-    vertices: torch.Tensor  # [V_r, 3] f32, already in bounding-box coordinates of the FULL grid
-    faces: torch.Tensor     # [F_r, 3] i32, GLOBAL vertex ids (vertices of all ranks concatenated in rank order)
-    vertex_base: int
-    counts: List[Tuple[int, int]]
+    """vertices: [V_r, 3] f32, already in bounding-box coordinates of the FULL grid
+    faces:    [F_r, 3] i32, GLOBAL vertex ids (vertices of all ranks concatenated in rank order)
+    counts / vertex_base: (V, F) of every rank and this rank's first global vertex id; when the extraction kept the
+    all-gathered counts on the device they are copied to the host on first access (a synchronisation)."""
+
+    def __init__(self, vertices, faces, vertex_base=None, counts=None, rank=None, rank_counts=None):
+        self.vertices, self.faces = vertices, faces
+        self._base, self._counts, self._rank, self._rank_counts = vertex_base, counts, rank, rank_counts
+
+    @property
+    def counts(self) -> List[Tuple[int, int]]:
+        if self._counts is None:
+            self._counts = [(int(c[0]), int(c[1])) for c in self._rank_counts.view(-1, 2).cpu()]
+        return self._counts
+
+    @property
+    def vertex_base(self) -> int:
+        if self._base is None:
+            self._base = sum(c[0] for c in self.counts[:self._rank])
+        return self._base
 
     def __iter__(self):  # (vertices, faces) unpacking like the single-GPU call
         return iter((self.vertices, self.faces))
@@ -198,6 +222,15 @@ class SlabExtractor:
             w.wait()
         nv, nf = self.phase_extract(thresh, lower, upper)
         mine = torch.tensor([nv, nf], dtype=torch.int64, device=self.grid.device)
+        if hasattr(self.backend, "faces_from_rank_counts"):
+            # the counts of the other ranks never visit the host: the face kernel derives its id bases from the
+            # all-gathered tensor, and both collectives are only stream-ordered before it
+            rank_counts = torch.empty(2 * self.world, dtype=torch.int64, device=self.grid.device)
+            dist.all_gather_into_tensor(rank_counts, mine)
+            for w in shift_to_prev(self.records_send_buffer(), self.records_recv_buffer()):
+                w.wait()
+            faces = self.backend.faces_from_rank_counts(rank_counts, self.rank)
+            return SlabResult(self._verts, faces, rank=self.rank, rank_counts=rank_counts)
         allc = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(allc, mine)
         counts = [(int(c[0]), int(c[1])) for c in torch.stack(allc).cpu()]

@@ -12,8 +12,9 @@ from tests.ws_keys import vertex_keys_from_workspace
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("device_bases", [False, True])
 @pytest.mark.parametrize("world", [2, 3, 4])
-def test_slabs_merge_to_the_whole_grid_mesh(gpu, world):
+def test_slabs_merge_to_the_whole_grid_mesh(gpu, world, device_bases):
     from primitive3d_amd import capi
     from primitive3d_amd.fields import perlin_grid
     from primitive3d_amd.slab import SlabExtractor, slab_bounds
@@ -30,7 +31,13 @@ def test_slabs_merge_to_the_whole_grid_mesh(gpu, world):
     counts = [e.phase_extract(thresh, lower, upper) for e in exs]
     for r in range(world - 1):
         exs[r].records_recv_buffer().copy_(exs[r + 1].records_send_buffer())
-    res = [e.phase_faces(counts) for e in exs]
+    if device_bases:  # the id bases come from the all-gathered counts ON THE DEVICE (p3d_mc_slab.rank_counts)
+        from primitive3d_amd.slab import SlabResult
+        rank_counts = torch.tensor(counts, dtype=torch.int64, device=gpu).reshape(-1)
+        res = [SlabResult(e._verts, e.backend.faces_from_rank_counts(rank_counts, e.rank), rank=e.rank,
+                          rank_counts=rank_counts) for e in exs]
+    else:
+        res = [e.phase_faces(counts) for e in exs]
     torch.cuda.synchronize()
 
     rx, ry, rz = shape
