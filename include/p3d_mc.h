@@ -126,11 +126,16 @@ int p3d_mc_extract_fused(const void* grid, int dtype, int64_t rx, int64_t ry, in
 int p3d_mc_debug_layout(int64_t rx, int64_t ry, int64_t rz, size_t* off_bits, size_t* off_records,
                         int64_t* num_units, int32_t* chunks_per_row);
 
-/* Multi-GPU helpers: location and size of the per-plane vertex-id records inside `ws`, so the host
- * can ship the next rank's plane-0 records into this rank's halo plane (RCCL send/recv of
- * `bytes_per_plane` bytes).  plane is a local axis-0 index. */
+/* Multi-GPU helpers.  A rank's halo plane (local plane rx-1, p3d_mc_slab.halo_last_plane) is the next rank's plane 0:
+ * that rank exports the vertex-id records of its plane 0 in dense form (p3d_mc_export_plane_records: `out` receives
+ * bytes_per_plane bytes; after a one-pass call the records inside ws are still region-relative, the export
+ * translates them), they travel over RCCL send/recv, and the receiver stores them at the location
+ * p3d_mc_plane_records returns for its plane rx-1 before it calls p3d_mc_emit for its faces.  plane is a local
+ * axis-0 index. */
 int p3d_mc_plane_records(void* ws, int64_t rx, int64_t ry, int64_t rz, int64_t plane,
                          void** records, size_t* bytes_per_plane);
+int p3d_mc_export_plane_records(const void* ws, int64_t rx, int64_t ry, int64_t rz, int64_t plane, void* out,
+                                void* stream);
 
 /* Measurement hooks (no reference counterpart; the reference's only instrumentation is the wall-clock
  * Timer of prim3d/misc/utils.py:41-116).  mode 0 = off, 1 = hipEvents around the dominant kernel

@@ -12,7 +12,7 @@ P3D_OK = 0
 
 # every symbol include/p3d_mc.h declares
 SYMBOLS = ("p3d_mc_abi_version", "p3d_last_error", "p3d_mc_workspace_bytes", "p3d_mc_count",
-           "p3d_mc_read_counts", "p3d_mc_emit", "p3d_mc_plane_records", "p3d_mc_profile_enable",
+           "p3d_mc_read_counts", "p3d_mc_emit", "p3d_mc_plane_records", "p3d_mc_export_plane_records", "p3d_mc_profile_enable",
            "p3d_mc_profile_read", "p3d_mc_profile_stage_name", "p3d_mc_extract_fused", "p3d_mc_debug_layout")
 
 
@@ -195,6 +195,13 @@ def plane_records(ws, rx, ry, rz, plane):
     _check(lib().p3d_mc_plane_records(c_void_p(ws.data_ptr()), rx, ry, rz, plane, byref(ptr), byref(n)),
            "p3d_mc_plane_records")
     return ptr.value, n.value
+
+
+def export_plane_records(ws, rx, ry, rz, plane, out):
+    """Dense vertex-id records of one plane -> `out` (uint8 tensor of bytes_per_plane bytes)."""
+    _check(lib().p3d_mc_export_plane_records(c_void_p(ws.data_ptr()), rx, ry, rz, plane, c_void_p(out.data_ptr()),
+                                             _stream_ptr(ws)), "p3d_mc_export_plane_records")
+    return out
 
 
 def extract(grid, thresh, lower=None, upper=None, with_keys=False):

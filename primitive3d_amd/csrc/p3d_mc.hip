@@ -421,7 +421,9 @@ __global__ void __launch_bounds__(kBlock) k_emit_vertices(const T* __restrict__ 
 // Corner bit weights and edge numbering follow marching_cubes.cu:49-57 and :178-192.
 // ---------------------------------------------------------------------------------------------
 struct FaceArgs {
-    int xlate;  // rec[].x is region * 2^26 + slot (straight from the streaming kernel): make it dense on the fly
+    int xlate;  // rec[].x may be region * 2^26 + slot (straight from the streaming kernel) and is made dense on the fly:
+                // 0 never; 1 yes, region bases from the call's cursors (the header is not finished yet);
+                // 2 if hdr[H_RECFORM] says so, region bases from hdr[H_PREFIX] (a later p3d_mc_emit)
     int halo_last;
     int64_t vid_base, halo_vid_base;
     const int64_t* rank_counts;  // optional: all-gathered {V, F} of all ranks on the device; bases are derived from it
@@ -548,6 +550,22 @@ __global__ void __launch_bounds__(kBlock) k_face_total(const u32* __restrict__ c
     }
 }
 
+// Dense copy of one plane's vertex-id records (the multi-GPU path ships the first plane to the previous rank, whose
+// halo plane it is).  After a one-pass call rec[] still holds region-form ids: translated here with the region
+// prefixes of the header.
+__global__ void __launch_bounds__(kBlock) k_export_plane_records(const uint2* __restrict__ rec, int64_t first,
+                                                                 int64_t n, const u64* __restrict__ hdr,
+                                                                 uint2* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    uint2 r = rec[first + i];
+    if (hdr[H_RECFORM] != 0ull) {
+        const u32 reg = r.x >> 26;
+        if (reg < (u32)kRegions) r.x = (r.x & 0x3ffffffu) + (u32)hdr[H_PREFIX + reg];
+    }
+    out[i] = r;
+}
+
 // Compaction of the streaming kernel's 32 vertex regions, riding in the face kernel's launch: its first
 // `nblocks` blocks copy while the other blocks emit faces (a bandwidth-bound and an ALU-bound job side by side,
 // one stream, no events).  Block j serves region j % 32, slice j / 32.  16-byte vectors aligned on the
@@ -668,14 +686,18 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     __shared__ u32 s_pref[kRegions];
     __shared__ u32 s_tmp[4];
 
-    const bool XLATE = a.xlate != 0;
+    const bool XLATE = a.xlate == 1 || (a.xlate == 2 && hdr[H_RECFORM] != 0ull);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     s_tab[tid] = g_tri_packed[tid];
     s_ntri[tid] = g_tri_count[tid];
     if (XLATE && wave == 0) {  // dense base of every region = exclusive prefix over the region cursors
-        const u32 cnt = lane < kRegions ? (u32)a.cursors[lane * kCursorStride] : 0u;
-        const u32 inc = wave_prefix_sum(cnt);
-        if (lane < kRegions) s_pref[lane] = inc - cnt;
+        if (a.xlate == 1) {
+            const u32 cnt = lane < kRegions ? (u32)a.cursors[lane * kCursorStride] : 0u;
+            const u32 inc = wave_prefix_sum(cnt);
+            if (lane < kRegions) s_pref[lane] = inc - cnt;
+        } else if (lane < kRegions) {
+            s_pref[lane] = (u32)hdr[H_PREFIX + lane];
+        }
     }
     auto dense = [&](u32 v) -> u32 { return XLATE ? (v & 0x3ffffffu) + s_pref[(v >> 26) & (kRegions - 1)] : v; };
 
@@ -798,7 +820,9 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
                     const u64 Cx0 = W0 ^ W1, Cx3 = W3 ^ W2;   // axis-0 edges of columns (x,y) and (x,y+1)
                     const u64 Cy0 = W0 ^ W3, Cy1 = W1 ^ W2;   // axis-1 edges of columns (x,y) and (x+1,y)
                     const uint2 r0 = s_r[0][t], r1 = s_r[1][t], r2 = s_r[2][t], r3 = s_r[3][t];
-                    const u32 v0 = dense(r0.x) + b0, v1 = dense(r1.x) + bh, v2 = dense(r2.x) + bh, v3 = dense(r3.x) + b0;
+                    // (records of an imported halo plane arrive dense, in the neighbour's numbering)
+                    const u32 v0 = dense(r0.x) + b0, v1 = (xhalo ? r1.x : dense(r1.x)) + bh;
+                    const u32 v2 = (xhalo ? r2.x : dense(r2.x)) + bh, v3 = dense(r3.x) + b0;
                     u32 id[12];
                     // edges at z (ranks among the bits below z)
                     id[0] = v0 + (u32)popc64(Cx0 & lowm);
@@ -818,7 +842,7 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
                         id[4] = m0;
                         id[6] = dense(n3.x) + b0;
                         id[7] = m0 + (n0.y & 0xffffu);
-                        id[5] = dense(n1.x) + bh + (n1.y & 0xffffu);
+                        id[5] = (xhalo ? n1.x : dense(n1.x)) + bh + (n1.y & 0xffffu);
                     }
                     // axis-2 edges of the 4 columns (always inside this chunk)
                     const u64 S0 = (W0 >> 1) | ((u64)(nbm & 1) << 63), S1 = (W1 >> 1) | ((u64)((nbm >> 1) & 1) << 63);
@@ -1105,10 +1129,10 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
     uint2* rec = (uint2*)(ws + w.rec);
     u32* cnt = (u32*)(ws + w.cnt);
     u64* hdr = (u64*)(ws + w.hdr);
-    // a one-pass call leaves the records in region form: make them dense now
-    hipLaunchKernelGGL(k_fix_records, dim3((u32)w.nb_v), dim3(256), 0, st, rec, d.U, hdr, 1);
-    HIP_TRY(hipMemsetAsync(hdr + H_RECFORM, 0, sizeof(u64), st));
     if (capv > 0) {
+        // a one-pass call leaves the records in region form: the gather emitter wants them dense
+        hipLaunchKernelGGL(k_fix_records, dim3((u32)w.nb_v), dim3(256), 0, st, rec, d.U, hdr, 1);
+        HIP_TRY(hipMemsetAsync(hdr + H_RECFORM, 0, sizeof(u64), st));
         // per-unit crossing counts select the units to visit; recomputed here (12 us at 512^3) because the
         // fused streaming kernel does not materialise them
         hipLaunchKernelGGL(k_unit_counts, dim3((u32)w.nb_v), dim3(kBlock), 0, st, bits, d, halo, cnt,
@@ -1119,7 +1143,7 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
     }
     if (w.nb_f > 0 && capf > 0) {
         StageTimer tm(ST_EMIT_FACES, st);
-        const FaceArgs a{0, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
+        const FaceArgs a{2, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
                          slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw,
                          (const u32*)(ws + w.chunk_sum), (const u32*)(ws + w.wave_off), nullptr, nullptr, 0};
         const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr};
@@ -1205,30 +1229,6 @@ Xform make_xform(const Dims& d, const float lower[3], const float upper[3], cons
     return t;
 }
 
-// The region compaction (pure copy, bandwidth bound) does not feed the face pass (latency bound): it runs on a
-// side stream between two events so the two overlap.  One side stream + event pair per device, created lazily.
-struct SideStream {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-};
-SideStream* side_stream_for_current_device() {
-    static SideStream tab[64];
-    static std::mutex mu;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> g(mu);
-    SideStream& s = tab[dev];
-    if (!s.stream) {
-        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) {
-            s.stream = nullptr;
-            return nullptr;
-        }
-    }
-    return &s;
-}
-
 template <typename T>
 int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xform& t, const p3d_mc_slab* slab,
                char* ws, float* verts, int64_t capv, float* scratch, int64_t scratch_rows, int32_t* faces,
@@ -1238,9 +1238,8 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     u64* bits = (u64*)(ws + w.bits);
     uint2* rec = (uint2*)(ws + w.rec);
     u32 *csum = (u32*)(ws + w.chunk_sum), *woff = (u32*)(ws + w.wave_off);
-    u64* prefix = hdr + H_PREFIX;
     // Vertex ids handed out by the streaming kernel are region * 2^26 + slot (a fixed stride, so they stay
-    // unambiguous even when a region outgrows its share of the scratch buffer); k_fix_records makes them dense.
+    // unambiguous even when a region outgrows its share of the scratch buffer); readers make them dense on the fly.
     // Storage is store_rows rows per region; without a scratch buffer nothing is stored (pure count + ids).
     const u32 region_rows = 1u << 26;
     const u32 store_rows = scratch ? (u32)std::min<int64_t>(scratch_rows / kRegions, (int64_t)region_rows) : 0u;
@@ -1263,14 +1262,11 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         HIP_TRY(hipGetLastError());
         return P3D_OK;
     }
-    // What follows the streaming kernel:
-    //  * face buffer given, no halo plane (the single-GPU call): two kernels on the caller's stream,
-    //      k_face_count_walk -> k_faces
-    //    The first blocks of the k_faces launch copy the vertex regions to their dense place and finish the header
-    //    (V, F, flags, region prefixes); the records stay in region form and k_faces makes them dense on the fly.
-    //  * otherwise (slab with a halo plane, or counting only): the ids must become dense in rec[] because
-    //    p3d_mc_emit / the neighbour rank read them later.  Region prefix -> k_fix_records -> compaction run on a
-    //    side stream next to k_face_count_walk -> k_face_total.
+    // What follows the streaming kernel, on the caller's stream: k_face_count_walk -> k_faces.  The first blocks of
+    // the k_faces launch copy the vertex regions to their dense place and finish the header (V, F, flags, region
+    // prefixes); the records stay in region form and k_faces makes them dense on the fly.  Without a face buffer, or
+    // with a halo plane (its records arrive later: the faces are then written by p3d_mc_emit), the launch consists of
+    // those first blocks only.
     const bool faces_here = w.nb_f > 0 && capf > 0 && !halo;
     u64 seq = 0;
     u64* mb = mailbox_open(ws, &seq);
@@ -1279,43 +1275,16 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         hipLaunchKernelGGL(k_face_count_walk<8>, dim3((u32)w.nchunks), dim3(kBlock), 0, st, bits, d, w.tpp, w.xw, csum,
                            woff);
     }
-    if (faces_here) {
-        const bool copy = scratch && capv > 0;
-        const FaceArgs a{1, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
-                         slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw,
-                         csum, woff, cursors, mb, seq};
-        const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows,
-                             copy ? std::max(1, env_int("P3D_COMPACT_BLOCKS", 256) / kRegions) * kRegions : kRegions,
-                             csum, (int)w.nchunks, cursors};
-        StageTimer tm(ST_EMIT_FACES, st);
-        hipLaunchKernelGGL(k_faces, dim3((u32)(w.nb_f + cp.nblocks)), dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr,
-                           faces, capf);
-        HIP_TRY(hipGetLastError());
-        return P3D_OK;
-    }
-
-    SideStream* side = env_int("P3D_NO_SIDE_STREAM", 0) ? nullptr : side_stream_for_current_device();
-    hipStream_t fs = st;  // stream of the finalize chain
-    if (side) {
-        HIP_TRY(hipEventRecord(side->fork, st));
-        HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
-        fs = side->stream;
-    }
-    {
-        StageTimer tm(ST_FINALIZE, fs);
-        hipLaunchKernelGGL(k_region_prefix, dim3(1), dim3(64), 0, fs, hdr, cursors, prefix,
-                           scratch ? store_rows : region_rows, 0, mb, seq);
-        hipLaunchKernelGGL(k_fix_records, dim3((u32)w.nb_v), dim3(256), 0, fs, rec, d.U, hdr, 0);
-    }
-    if (scratch && capv > 0)
-        hipLaunchKernelGGL(k_compact, dim3(64, kRegions), dim3(256), 0, fs, scratch, cursors, prefix, store_rows, verts,
-                           capv);
-    if (side) HIP_TRY(hipEventRecord(side->join, fs));
-    {
-        StageTimer tm(ST_SCAN_F, st);
-        hipLaunchKernelGGL(k_face_total, dim3(1), dim3(kBlock), 0, st, csum, (int)w.nchunks, hdr, mb, seq);
-    }
-    if (side) HIP_TRY(hipStreamWaitEvent(st, side->join, 0));  // the caller's stream owns both outputs again
+    const bool copy = scratch && capv > 0;
+    const FaceArgs a{1, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
+                     slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw,
+                     csum, woff, cursors, mb, seq};
+    const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows,
+                         copy ? std::max(1, env_int("P3D_COMPACT_BLOCKS", 256) / kRegions) * kRegions : kRegions,
+                         csum, (int)w.nchunks, cursors};
+    StageTimer tm(ST_EMIT_FACES, st);
+    hipLaunchKernelGGL(k_faces, dim3((u32)((faces_here ? w.nb_f : 0) + cp.nblocks)), dim3(kBlock), 0, st, bits, rec, d, a,
+                       cp, hdr, faces, capf);
     HIP_TRY(hipGetLastError());
     return P3D_OK;
 }
@@ -1459,6 +1428,20 @@ int p3d_mc_plane_records(void* ws, int64_t rx, int64_t ry, int64_t rz, int64_t p
     const Ws w = make_ws(d);
     *records = (char*)ws + w.rec + (size_t)plane * d.P * sizeof(uint2);
     *bytes_per_plane = (size_t)d.P * sizeof(uint2);
+    return P3D_OK;
+}
+
+int p3d_mc_export_plane_records(const void* ws, int64_t rx, int64_t ry, int64_t rz, int64_t plane, void* out,
+                                void* stream) {
+    if (!ws || !out) return fail(P3D_EINVAL, "null pointer%s");
+    if (int rc = check_dims(rx, ry, rz)) return rc;
+    if (plane < 0 || plane >= rx) return fail(P3D_EINVAL, "plane out of range%s");
+    const Dims d = make_dims(rx, ry, rz);
+    const Ws w = make_ws(d);
+    hipLaunchKernelGGL(k_export_plane_records, dim3((u32)((d.P + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, (const uint2*)((const char*)ws + w.rec), plane * d.P, d.P,
+                       (const u64*)((const char*)ws + w.hdr), (uint2*)out);
+    HIP_TRY(hipGetLastError());
     return P3D_OK;
 }
 

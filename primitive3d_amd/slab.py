@@ -92,7 +92,10 @@ class HipBackend:
         return ws[off:off + nbytes]
 
     def export_first_plane_records(self):
-        return self._plane_view(0)
+        grid, ws = self._state[0], self._state[5]
+        _, nbytes = self.capi.plane_records(ws, *grid.shape, 0)
+        out = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self.capi.export_plane_records(ws, *grid.shape, 0, out)
 
     def halo_records_buffer(self):
         return self._plane_view(self._state[0].shape[0] - 1)
