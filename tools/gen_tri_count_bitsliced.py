@@ -5,13 +5,18 @@ The number of triangles of a marching-cubes cell (0..5, P3D_TRI_COUNT in tri_tab
 the reference's case table by tools/gen_tri_table.py) is a function of the 8 corner signs.  With lane = unit the 8
 signs of the 64 cells of a unit are 8 machine words, so the three bits of the count can be computed for all cells
 of the unit at once by a boolean network: v_bitop3_b32 (any 3-input function, new on gfx950) for the leaves and
-the 2:1 selects: leaves = functions of (x0, x1, x2), selects on x3..x7, common subterms shared.  (The table is not
-symmetric under complementing all signs, so no variable can be folded away.)
+the 2:1 selects, common subterms shared.  Which three variables feed the leaves and the order of the five select
+variables were found by exhaustive search over all 6720 choices (LEAF_VARS / SELECT_ORDER below: 84 operations; the
+natural order x0..x7 needs 100).  The table is not symmetric under complementing all signs, so no variable can be
+folded away.
 The generator verifies the network against the table for all 256 masks before writing it.
 """
 import re
 import sys
 from pathlib import Path
+
+LEAF_VARS = (0, 1, 6)            # leaves are functions of these corner signs
+SELECT_ORDER = (7, 2, 3, 4, 5)    # 2:1 selects, innermost first
 
 ROOT = Path(__file__).resolve().parents[1]
 INC = ROOT / "primitive3d_amd" / "csrc" / "tri_table_packed.inc"
@@ -44,7 +49,7 @@ class Net:
             return 0
         if imm == 0xFF:
             return 1
-        return self.new(f"P3D_BITOP3(x2, x1, x0, 0x{imm:02x})", ("leaf", imm))
+        return self.new(f"P3D_BITOP3(x{LEAF_VARS[2]}, x{LEAF_VARS[1]}, x{LEAF_VARS[0]}, 0x{imm:02x})", ("leaf", imm))
 
     def mux(self, s, a, b):  # s ? a : b
         if a == b:
@@ -94,17 +99,22 @@ def main() -> int:
         net.cse_muxes = cse_muxes
         outs = []
         for o in range(3):
-            def node(level, sel):  # function of x0..x(2+level) with the higher variables fixed to `sel`
+            def node(level, assign):  # function of the leaf variables and the first `level` select variables
                 if level == 0:
                     imm = 0
                     for low in range(8):
-                        imm |= ((ntri[low | (sel << 3)] >> o) & 1) << low
+                        m = 0
+                        for bi, v in enumerate(LEAF_VARS):
+                            m |= ((low >> bi) & 1) << v
+                        for v, val in assign.items():
+                            m |= val << v
+                        imm |= ((ntri[m] >> o) & 1) << low
                     return net.leaf(imm)
-                hi = node(level - 1, (sel << 1) | 1)   # depth first: few values alive at any time
-                lo = node(level - 1, (sel << 1) | 0)
-                return net.mux(f"x{2 + level}", hi, lo)
-            # variable order: x7 is the top select, x3 the lowest; sel accumulates x7..x3 from the top
-            outs.append(node(5, 0))
+                v = SELECT_ORDER[level - 1]
+                hi = node(level - 1, {**assign, v: 1})   # depth first: few values alive at any time
+                lo = node(level - 1, {**assign, v: 0})
+                return net.mux(f"x{v}", hi, lo)
+            outs.append(node(5, {}))
         return net, outs
 
     def fix_sel_order(ntri_):
