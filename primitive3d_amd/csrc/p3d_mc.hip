@@ -453,6 +453,9 @@ __device__ inline void wave_lds_sync() {  // orders one wave's LDS traffic acros
 // divergence.  Output: wave_off[(x * tpp + tile) * 4 + w] = triangles of the chunk before wave w of that tile,
 // chunk_sum[chunk] = chunk total.  No scan follows: k_faces adds the chunk totals up itself.
 // Replaces the atomicAdd(counters + 1, ...) of marching_cubes.cu:60-65.
+#ifndef P3D_COUNT_PB
+#define P3D_COUNT_PB 8   // planes per sub-batch of k_face_count_walk
+#endif
 template <int PB>
 __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restrict__ bits, Dims d, int64_t tpp, int xw,
                                                             u32* __restrict__ chunk_sum, u32* __restrict__ wave_off) {
@@ -667,6 +670,9 @@ __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr
 // s_waitcnt vmcnt would wait for the stores in flight too).  With a.xlate the records are read in the streaming
 // kernel's region form (region * 2^26 + slot) and made dense on the fly from the 32 region cursors, so no pass over
 // the records has to precede the faces.
+// NHALO: units staged beyond the tile's 256 for the y+1 columns -- 32 (rows of at most 32 chunks, rz <= 2048: 31.6 KiB
+// of LDS, five tiles per CU) or 256 (any row length: four tiles per CU).
+template <int NHALO>
 __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, const uint2* __restrict__ rec, Dims d,
                                                   FaceArgs a, CompactArgs cp, u64* __restrict__ hdr,
                                                   int32_t* __restrict__ faces, int64_t cap_faces) {
@@ -674,11 +680,14 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
         compact_block(cp, hdr, a.mb, a.seq);
         return;
     }
+    // staged units per plane: the tile, its y+1 halo and one more unit (z+1 of the last); rows longer than NHALO
+    // chunks use two separate ranges of 257
+    constexpr int NS = (kBlock + NHALO + 1) > 2 * (kBlock + 1) ? (kBlock + NHALO + 1) : (NHALO >= kBlock ? 2 * (kBlock + 1) : kBlock + NHALO + 1);
     __shared__ u64 s_tab[256];
     __shared__ unsigned char s_ntri[256];
-    __shared__ u64 s_w[4][kBlock];                       // W00,W10,W11,W01: bit k = sign of corner column j at z = 64c+k
-    __shared__ unsigned char s_nb[kBlock];               // bit j = sign of column j at the first voxel of the next chunk
-    __shared__ uint2 s_r[4][kBlock + 1];                 // vertex-id records of the 4 owner columns (+ the unit after the tile)
+    __shared__ u64 s_w[2][NS];                           // sign words of planes x and x+1 (bit k = sign at z = 64c+k)
+    __shared__ uint2 s_r[2][NS];                         // their vertex-id records
+    __shared__ unsigned char s_nb[kBlock];               // per unit: bit j = sign of column j at the first voxel of the next chunk
     __shared__ unsigned short s_cells[4][kWaveCells];    // per wave: active cells of the round, unit-in-tile << 6 | z
     __shared__ u32 s_ids[4][12][64];                     // per wave: vertex ids of the batch's cells' 12 edges
     __shared__ unsigned short s_tri[4][320];             // per wave: triangle -> cell-in-batch << 3 | slot
@@ -707,48 +716,26 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     const int64_t p = tile * kBlock + tid;
     const int64_t y = p / d.ncz;
     const int c = (int)(p - y * d.ncz);
-    const int64_t u = x * d.P + p;
     const bool valid = (p < d.P) && (y + 1 < d.ry);  // x+1 < rx by grid construction
     const bool more = c + 1 < d.ncz;
 
-    // phase A
-    const int64_t uc[4] = {u, u + d.P, u + d.P + d.ncz, u + d.ncz};
-    u64 W[4] = {0, 0, 0, 0};
-    if (valid) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            W[k] = bits[uc[k]];
-            s_r[k][tid] = rec[uc[k]];  // only entries of units that own vertices are meaningful
+    // phase A: the units [tile start, +256) of planes x and x+1, the same ranges one row up (y+1: "+ncz" units, or a
+    // second range of 256 when a row is longer than NHALO chunks), and one unit more (the z+1 neighbour of the last).
+    // A cell's four columns W00,W10,W11,W01 are then plane 0/1 at index t and t + hoff.
+    const bool one_range = d.ncz <= NHALO;
+    const int hoff = one_range ? d.ncz : kBlock + 1;   // index distance of the y+1 column
+    const int nstage = one_range ? kBlock + d.ncz + 1 : 2 * (kBlock + 1);
+    const int64_t p0 = tile * kBlock;
+    for (int i = tid; i < nstage; i += kBlock) {
+        const int64_t pi = (one_range || i <= kBlock) ? p0 + i : p0 + d.ncz + (i - kBlock - 1);
+        const bool ex = pi < d.P;
+        const int64_t ui = x * d.P + pi;
+        s_w[0][i] = ex ? bits[ui] : 0ull;
+        s_w[1][i] = ex ? bits[ui + d.P] : 0ull;
+        if (ex) {
+            s_r[0][i] = rec[ui];  // only entries of units that own vertices are meaningful
+            s_r[1][i] = rec[ui + d.P];
         }
-    }
-    // the record of the unit that follows the tile's last one (its cells at z = 63 continue there) is staged too
-    if (tid == kBlock - 1 && valid && more) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s_r[k][kBlock] = rec[uc[k] + 1];
-    }
-    // first bit of the next chunk of each column: the next lane holds it (same row), the wave's last lane loads it
-    const int first4 = (int)((W[0] & 1ull) | ((W[1] & 1ull) << 1) | ((W[2] & 1ull) << 2) | ((W[3] & 1ull) << 3));
-    int nbits = __shfl_down(first4, 1, 64);
-    if (lane == 63) {
-        nbits = 0;
-        if (valid && more) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) nbits |= (int)(bits[uc[k] + 1] & 1ull) << k;
-        }
-    }
-    if (!more) nbits = 0;
-    u64 act_all = 0;
-    {
-        u64 orr = 0, andd = ~0ull;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const u64 S = (W[k] >> 1) | ((u64)((nbits >> k) & 1) << 63);
-            s_w[k][tid] = W[k];
-            orr |= W[k] | S;
-            andd &= W[k] & S;
-        }
-        s_nb[tid] = (unsigned char)nbits;
-        if (valid) act_all = orr & ~andd & zedge(d, c);
     }
     // faces of the chunks before this tile's chunk (summed by the whole block)
     {
@@ -761,13 +748,35 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     __syncthreads();  // the only block barrier: staging done (no store is in flight yet)
     int64_t wrun = (int64_t)(s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3]) + (int64_t)a.wave_off[b * 4 + wave];
 
+    // column k of unit t: (plane, index)
+    auto colw = [&](int k, int t) -> u64 { return s_w[(k == 1 || k == 2) ? 1 : 0][t + (k >= 2 ? hoff : 0)]; };
+    auto colr = [&](int k, int t) -> uint2 { return s_r[(k == 1 || k == 2) ? 1 : 0][t + (k >= 2 ? hoff : 0)]; };
+    // per unit (lane = unit of this wave): next-chunk bits, active cells
+    u64 act_all = 0;
+    {
+        int nbits = 0;
+        u64 orr = 0, andd = ~0ull;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u64 Wk = valid ? colw(k, tid) : 0ull;
+            const u64 nb = (valid && more) ? (colw(k, tid + 1) & 1ull) : 0ull;
+            const u64 S = (Wk >> 1) | (nb << 63);
+            nbits |= (int)nb << k;
+            orr |= Wk | S;
+            andd &= Wk & S;
+        }
+        s_nb[tid] = (unsigned char)nbits;
+        if (valid) act_all = orr & ~andd & zedge(d, c);
+    }
+    wave_lds_sync();  // s_nb of this wave's units is read by this wave's cell lanes
+
     // corner mask of a cell: bits 0-3 = columns at z, bits 4-7 = the same columns at z+1
     auto cell_mask = [&](int t, int z) {
         int lo = 0, hi = 0;
         const int nbm = s_nb[t];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const u64 Wk = s_w[k][t];
+            const u64 Wk = colw(k, t);
             lo |= (int)((Wk >> z) & 1ull) << k;
             hi |= (z < 63 ? (int)((Wk >> (z + 1)) & 1ull) : ((nbm >> k) & 1)) << k;
         }
@@ -814,12 +823,12 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
                 nt = s_ntri[mask];
                 if (nt) {
                     // crossing words of the 4 columns within this chunk
-                    const u64 W0 = s_w[0][t], W1 = s_w[1][t], W2 = s_w[2][t], W3 = s_w[3][t];
+                    const u64 W0 = colw(0, t), W1 = colw(1, t), W2 = colw(2, t), W3 = colw(3, t);
                     const int nbm = s_nb[t];
                     const u64 lowm = below(z);
                     const u64 Cx0 = W0 ^ W1, Cx3 = W3 ^ W2;   // axis-0 edges of columns (x,y) and (x,y+1)
                     const u64 Cy0 = W0 ^ W3, Cy1 = W1 ^ W2;   // axis-1 edges of columns (x,y) and (x+1,y)
-                    const uint2 r0 = s_r[0][t], r1 = s_r[1][t], r2 = s_r[2][t], r3 = s_r[3][t];
+                    const uint2 r0 = colr(0, t), r1 = colr(1, t), r2 = colr(2, t), r3 = colr(3, t);
                     // (records of an imported halo plane arrive dense, in the neighbour's numbering)
                     const u32 v0 = dense(r0.x) + b0, v1 = (xhalo ? r1.x : dense(r1.x)) + bh;
                     const u32 v2 = (xhalo ? r2.x : dense(r2.x)) + bh, v3 = dense(r3.x) + b0;
@@ -836,8 +845,8 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
                         id[7] = id[3] + (u32)((Cy0 >> z) & 1ull);
                         id[5] = id[1] + (u32)((Cy1 >> z) & 1ull);
                     } else {
-                        // next chunk of the same row (c+1 < ncz is implied by a valid z+1): unit t+1, staged even for t = 255
-                        const uint2 n0 = s_r[0][t + 1], n1 = s_r[1][t + 1], n3 = s_r[3][t + 1];
+                        // next chunk of the same row (c+1 < ncz is implied by a valid z+1): the next staged unit
+                        const uint2 n0 = colr(0, t + 1), n1 = colr(1, t + 1), n3 = colr(3, t + 1);
                         const u32 m0 = dense(n0.x) + b0;
                         id[4] = m0;
                         id[6] = dense(n3.x) + b0;
@@ -1110,7 +1119,7 @@ int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3
     }
     if (w.nchunks > 0) {
         StageTimer tm(ST_FACES_COUNT, st);
-        hipLaunchKernelGGL(k_face_count_walk<8>, dim3((u32)w.nchunks), dim3(kBlock), 0, st, bits, d, w.tpp, w.xw, csum,
+        hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)w.nchunks), dim3(kBlock), 0, st, bits, d, w.tpp, w.xw, csum,
                            woff);
     }
     {
@@ -1147,7 +1156,10 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
                          slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw,
                          (const u32*)(ws + w.chunk_sum), (const u32*)(ws + w.wave_off), nullptr, nullptr, 0};
         const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr};
-        hipLaunchKernelGGL(k_faces, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, none, hdr, faces, capf);
+        if (d.ncz <= 32)
+            hipLaunchKernelGGL(k_faces<32>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, none, hdr, faces, capf);
+        else
+            hipLaunchKernelGGL(k_faces<256>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, none, hdr, faces, capf);
     }
     HIP_TRY(hipGetLastError());
     return P3D_OK;
@@ -1272,7 +1284,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     u64* mb = mailbox_open(ws, &seq);
     if (w.nchunks > 0) {
         StageTimer tm(ST_FACES_COUNT, st);
-        hipLaunchKernelGGL(k_face_count_walk<8>, dim3((u32)w.nchunks), dim3(kBlock), 0, st, bits, d, w.tpp, w.xw, csum,
+        hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)w.nchunks), dim3(kBlock), 0, st, bits, d, w.tpp, w.xw, csum,
                            woff);
     }
     const bool copy = scratch && capv > 0;
@@ -1283,8 +1295,11 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
                          copy ? std::max(1, env_int("P3D_COMPACT_BLOCKS", 256) / kRegions) * kRegions : kRegions,
                          csum, (int)w.nchunks, cursors};
     StageTimer tm(ST_EMIT_FACES, st);
-    hipLaunchKernelGGL(k_faces, dim3((u32)((faces_here ? w.nb_f : 0) + cp.nblocks)), dim3(kBlock), 0, st, bits, rec, d, a,
-                       cp, hdr, faces, capf);
+    const dim3 fgrid((u32)((faces_here ? w.nb_f : 0) + cp.nblocks));
+    if (d.ncz <= 32)
+        hipLaunchKernelGGL(k_faces<32>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
+    else
+        hipLaunchKernelGGL(k_faces<256>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
     HIP_TRY(hipGetLastError());
     return P3D_OK;
 }

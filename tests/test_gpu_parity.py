@@ -88,6 +88,16 @@ def test_fused_wide_rows_need_z_halo(gpu):
     _assert_same_mesh(hip, oracle_extract(g, 0.1))
 
 
+@pytest.mark.parametrize("shape", [(3, 3, 2100), (4, 2, 16450), (2, 9, 2049)])
+def test_long_rows_use_the_wide_face_staging(gpu, shape):
+    """rz > 2048 (rows of more than 32 chunks) selects k_faces<256>; rz > 16384 (more than 256 chunks per row) its
+    two-range staging; both through the counting call and the one-pass call."""
+    g = np.random.default_rng(sum(shape)).standard_normal(shape).astype(np.float32)
+    ref = oracle_extract(g, 0.2)
+    _assert_same_mesh(_hip_extract(gpu, g, 0.2, None, None), ref)
+    _assert_same_mesh(_hip_extract_fused(gpu, g, 0.2, None, None), ref)
+
+
 def test_fused_fp16(gpu):
     g = small_cases()["perlin48"][0].astype(np.float16)
     hip = _hip_extract_fused(gpu, g, 0.0, None, None, dtype=torch.float16)
