@@ -7,14 +7,14 @@ import sys
 from collections import defaultdict
 
 d = sys.argv[1]
-ours = ("k_fused", "k_faces", "k_face_count", "k_scan_blocks", "k_classify", "k_unit_counts", "k_unit_records", "k_emit_vertices", "k_region_prefix",
-        "k_fix_records", "k_compact")
+ours = ("k_fused", "k_face_count_walk", "k_face_total", "k_faces", "k_export_plane_records", "k_scan_blocks", "k_classify",
+        "k_unit_counts", "k_unit_records", "k_emit_vertices", "k_fix_records")
 
 
 def short(name):
     for o in ours:
-        if o in name:
-            return o + ("<emit>" if "ILb1E" in name or "<true>" in name else "<count>" if "k_faces" in name else "")
+        if o + "<" in name or o + "(" in name or name.endswith(o) or o + "I" in name or o + "E" in name:
+            return o
     return None
 
 
