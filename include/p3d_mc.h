@@ -81,10 +81,14 @@ int p3d_mc_workspace_bytes(int64_t rx, int64_t ry, int64_t rz, size_t* bytes);
 int p3d_mc_count(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz, float thresh,
                  const p3d_mc_slab* slab, void* ws, void* stream);
 
-/* Blocking read of the totals (replaces the two .item() calls, marching_cubes.cu:251-252).
- * num_faces is triangles, not indices.  scratch_overflow (nullable) is set to 1 when the scratch
- * buffer handed to p3d_mc_extract_fused was too small for some output region (the vertex buffer is
- * then incomplete and p3d_mc_emit must be used to rewrite it; ids and counts stay valid). */
+/* Read of the totals (replaces the two .item() calls, marching_cubes.cu:251-252) of the last p3d_mc_count /
+ * p3d_mc_extract_fused on this workspace.  It does NOT synchronise the stream: the kernels store the totals into
+ * a pinned, host-coherent mailbox slot as soon as they are known and this call polls the slot, so it returns
+ * while the remaining kernels of the call may still be running (results are complete in stream order).  Falls
+ * back to a 24-byte copy + hipStreamSynchronize when the mailbox is unavailable (P3D_NO_MAILBOX=1, no pinned
+ * memory, slot recycled by 64 newer calls).  num_faces is triangles, not indices.  scratch_overflow (nullable) is
+ * set to 1 when the scratch buffer handed to p3d_mc_extract_fused was too small for some output region (the
+ * vertex buffer is then incomplete and p3d_mc_emit must be used to rewrite it; ids and counts stay valid). */
 int p3d_mc_read_counts(const void* ws, int64_t* num_vertices, int64_t* num_faces, int32_t* scratch_overflow,
                        void* stream);
 

@@ -165,3 +165,25 @@ def test_medium_perlin_192(gpu):
     ref = oracle_extract(g, 0.0)
     assert hip[0].shape[0] == 268980 and hip[1].shape[0] == 531431
     _assert_same_mesh(hip, ref)
+
+
+def test_counts_without_the_mailbox(gpu):
+    """P3D_NO_MAILBOX=1 (read once per process): p3d_mc_read_counts falls back to copy + synchronise."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    code = ("import numpy as np, torch, sys; sys.path.insert(0, %r)\n"
+            "from primitive3d_amd import capi\n"
+            "from tests.cases import small_cases\n"
+            "g, t, lo, up = small_cases()['noise_33x17x200']\n"
+            "v, f = capi.extract_fused(torch.from_numpy(g).cuda(), t, lo, up)\n"
+            "v2, f2 = capi.extract(torch.from_numpy(g).cuda(), t, lo, up)[:2]\n"
+            "print(v.shape[0], f.shape[0], v2.shape[0], f2.shape[0])\n") % str(root)
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, "P3D_NO_MAILBOX": "1"}, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    g, t, _, _ = small_cases()["noise_33x17x200"]
+    nv, nf = oracle_count(g, t)
+    assert out.stdout.split() == [str(nv), str(nf), str(nv), str(nf)]
