@@ -437,7 +437,10 @@ struct FaceArgs {
     u64 seq;
 };
 
-constexpr int kWaveCells = 512;  // active cells a wave expands at a time (its 64 units have up to 4096)
+#ifndef P3D_WAVE_CELLS
+#define P3D_WAVE_CELLS 512
+#endif
+constexpr int kWaveCells = P3D_WAVE_CELLS;  // active cells a wave expands at a time (its 64 units have up to 4096)
 
 __device__ inline void wave_lds_sync() {  // orders one wave's LDS traffic across its lanes (no block barrier)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -664,8 +667,10 @@ __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr
 // (wave_off from k_face_count_walk + the chunk totals before its chunk).
 //   phase A (lane = unit, block) : the 2x2 column words, their next-chunk bits, vertex-id records -> LDS
 //   phase B (lane = unit, wave)  : dense list of the wave's active cells (8 z-octant rounds if it does not fit)
-//   phase C (lane = cell, wave)  : corner mask, the cell's 12 edge vertex ids -> the wave's LDS slice
-//   phase D (lane = TRIANGLE)    : three LDS lookups, 12 contiguous bytes stored per lane (fully coalesced)
+//   phase C (lane = cell, wave)  : corner mask, the cell's 12 edge vertex ids -> the lane's column of the wave's LDS
+//                                  slice, then the cell's triangles one per iteration (<= 5): three ids read back by
+//                                  table index, 12 bytes stored; a cell's faces are contiguous, consecutive cells
+//                                  adjacent (a lane-per-triangle second phase cost more instructions than it saved)
 // No block barrier and no global load sits between a face store and the next batch (a barrier's or a load's
 // s_waitcnt vmcnt would wait for the stores in flight too).  With a.xlate the records are read in the streaming
 // kernel's region form (region * 2^26 + slot) and made dense on the fly from the 32 region cursors, so no pass over
@@ -690,8 +695,6 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     __shared__ unsigned char s_nb[kBlock];               // per unit: bit j = sign of column j at the first voxel of the next chunk
     __shared__ unsigned short s_cells[4][kWaveCells];    // per wave: active cells of the round, unit-in-tile << 6 | z
     __shared__ u32 s_ids[4][12][64];                     // per wave: vertex ids of the batch's cells' 12 edges
-    __shared__ unsigned short s_tri[4][320];             // per wave: triangle -> cell-in-batch << 3 | slot
-    __shared__ unsigned char s_cm[4][64];                // per wave: corner mask of the batch's cells
     __shared__ u32 s_pref[kRegions];
     __shared__ u32 s_tmp[4];
 
@@ -867,20 +870,20 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
             const u32 inc = wave_prefix_sum(nt);
             const u32 o = inc - nt;
             const u32 batch_total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
-            s_cm[wave][lane] = (unsigned char)mask;
-            for (u32 k = 0; k < nt; ++k) s_tri[wave][o + k] = (unsigned short)((lane << 3) | k);
-            wave_lds_sync();
-            // phase D (lane = triangle)
-            for (u32 tix = lane; tix < batch_total; tix += 64) {
-                const int ref = s_tri[wave][tix];
-                const int ci = ref >> 3, k = ref & 7;
-                const u32 row3 = (u32)(s_tab[s_cm[wave][ci]] >> (12 * k));
-                const int64_t f = wrun + tix;
-                if (f < cap_faces) {
-                    int32_t* o3 = faces + f * 3;
-                    o3[0] = (int32_t)s_ids[wave][row3 & 15u][ci];
-                    o3[1] = (int32_t)s_ids[wave][(row3 >> 4) & 15u][ci];
-                    o3[2] = (int32_t)s_ids[wave][(row3 >> 8) & 15u][ci];
+            // the cell's own triangles, one per iteration: the three vertex ids come back out of the lane's LDS column
+            // (a register array cannot be indexed per lane); a cell's faces are contiguous, consecutive cells adjacent
+            {
+                const u64 row = s_tab[mask];
+                const int64_t f0 = wrun + o;
+                for (u32 k = 0; k < 5; ++k) {
+                    if (!__ballot(k < nt)) break;  // wave-uniform
+                    if (k < nt && f0 + k < cap_faces) {
+                        const u32 row3 = (u32)(row >> (12 * k));
+                        int32_t* o3 = faces + (f0 + k) * 3;
+                        o3[0] = (int32_t)s_ids[wave][row3 & 15u][lane];
+                        o3[1] = (int32_t)s_ids[wave][(row3 >> 4) & 15u][lane];
+                        o3[2] = (int32_t)s_ids[wave][(row3 >> 8) & 15u][lane];
+                    }
                 }
             }
             wrun += batch_total;
