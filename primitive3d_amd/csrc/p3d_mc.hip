@@ -669,9 +669,10 @@ __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr
 //   phase A (lane = unit, block) : the 2x2 column words, their next-chunk bits, vertex-id records -> LDS
 //   phase B (lane = unit, wave)  : dense list of the wave's active cells (8 z-octant rounds if it does not fit)
 //   phase C (lane = cell, wave)  : corner mask, the cell's 12 edge vertex ids -> the lane's column of the wave's LDS
-//                                  slice, then the cell's triangles one per iteration (<= 5): three ids read back by
-//                                  table index, 12 bytes stored; a cell's faces are contiguous, consecutive cells
-//                                  adjacent (a lane-per-triangle second phase cost more instructions than it saved)
+//                                  slice, then the k-th triangles of all cells together (k < 5): three ids read back
+//                                  by table index, one 12-byte streaming store per lane, the lanes that have a k-th
+//                                  triangle writing a dense run (a lane-per-triangle second phase cost more
+//                                  instructions than it saved)
 // No block barrier and no global load sits between a face store and the next batch (a barrier's or a load's
 // s_waitcnt vmcnt would wait for the stores in flight too).  With a.xlate the records are read in the streaming
 // kernel's region form (region * 2^26 + slot) and made dense on the fly from the 32 region cursors, so no pass over
@@ -868,26 +869,31 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
                     for (int e = 0; e < 12; ++e) s_ids[wave][e][lane] = id[e];
                 }
             }
-            const u32 inc = wave_prefix_sum(nt);
-            const u32 o = inc - nt;
-            const u32 batch_total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
-            // the cell's own triangles, one per iteration: the three vertex ids come back out of the lane's LDS column
-            // (a register array cannot be indexed per lane); a cell's faces are contiguous, consecutive cells adjacent
+            // the batch's triangles, k-th triangle of every cell together: the lanes that have one write a DENSE run
+            // (rank among them = position), so every store instruction covers contiguous bytes.  The three vertex ids
+            // come back out of the lane's LDS column by table index (a register array cannot be indexed per lane).
             {
                 const u64 row = s_tab[mask];
-                const int64_t f0 = wrun + o;
                 for (u32 k = 0; k < 5; ++k) {
-                    if (!__ballot(k < nt)) break;  // wave-uniform
-                    if (k < nt && f0 + k < cap_faces) {
+                    const u64 have = __ballot(k < nt);
+                    if (!have) break;  // wave-uniform
+                    const int64_t f = wrun + mbcnt64(have);
+                    if (k < nt && f < cap_faces) {
                         const u32 row3 = (u32)(row >> (12 * k));
-                        int32_t* o3 = faces + (f0 + k) * 3;
-                        o3[0] = (int32_t)s_ids[wave][row3 & 15u][lane];
-                        o3[1] = (int32_t)s_ids[wave][(row3 >> 4) & 15u][lane];
-                        o3[2] = (int32_t)s_ids[wave][(row3 >> 8) & 15u][lane];
+                        int32_t* o3 = faces + f * 3;
+                        // one 12-byte streaming store: the faces are never read again by this call, and keeping them
+                        // out of the caches lets the next call's streaming kernel start clean (-8 us on k_fused in a
+                        // back-to-back call stream; with the dense runs the stores fill whole sectors)
+                        typedef int i3u __attribute__((ext_vector_type(3), aligned(4)));
+                        i3u tv;
+                        tv.x = (int32_t)s_ids[wave][row3 & 15u][lane];
+                        tv.y = (int32_t)s_ids[wave][(row3 >> 4) & 15u][lane];
+                        tv.z = (int32_t)s_ids[wave][(row3 >> 8) & 15u][lane];
+                        __builtin_nontemporal_store(tv, (i3u*)o3);
                     }
+                    wrun += popc64(have);
                 }
             }
-            wrun += batch_total;
             wave_lds_sync();
         }
     }
