@@ -448,6 +448,99 @@ __device__ inline void wave_lds_sync() {  // orders one wave's LDS traffic acros
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Compaction of the streaming kernel's 32 vertex regions, riding in the launches of the two face kernels: their
+// first `nblocks` blocks copy while the other blocks count / emit faces (a bandwidth-bound job next to two
+// ALU-bound ones, one stream, no events).  Block j serves region j % 32, slice j / 32.  16-byte vectors aligned on the
+// destination; the source is read with 4-byte-aligned 16-byte loads.  Block 0 also finishes the header: V, F, the
+// overflow flag, the region prefixes, the record form flag, and publishes V and F to the host.
+struct CompactArgs {
+    const float* scratch;  // null: nothing to copy (counting call), the header is still finished
+    float* verts;
+    int64_t capv;
+    u32 store_rows, region_rows;
+    int nblocks;           // multiple of kRegions (0: no compaction blocks in this launch)
+    int part0, nparts;     // this launch copies slices part0 .. part0 + nblocks/32 - 1 of every region, out of nparts
+    int finish;            // block 0 also finishes the header and reports V and F
+    const u32* chunk_sum;  // block 0 adds the chunk sums up to F
+    int nchunks;
+    const u64* cursors;    // the call's cursor block
+};
+typedef float F4U __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access at 4-byte alignment
+typedef float F4A __attribute__((ext_vector_type(4)));
+__device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr, u64* mb, u64 seq) {
+    __shared__ u64 s_cur[kRegions], s_pre[kRegions];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 64) {
+        const u64 cur = lane < kRegions ? c.cursors[lane * kCursorStride] : 0ull;
+        u64 inc = cur;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u64 tt = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += tt;
+        }
+        if (lane < kRegions) {
+            s_cur[lane] = cur;
+            s_pre[lane] = inc - cur;
+        }
+        if (blockIdx.x == 0 && c.finish) {
+            const u64 over = __ballot(cur > (u64)(c.scratch ? c.store_rows : c.region_rows));
+            if (lane < kRegions) hdr[H_PREFIX + lane] = inc - cur;
+            if (lane == kRegions - 1) {
+                hdr[H_V] = inc;
+                hdr[H_FLAGS] = over ? 1ull : 0ull;
+                hdr[H_RECFORM] = 1ull;
+                mb_publish_v(mb, seq, inc, over ? 1ull : 0ull);
+            }
+        }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && c.finish) {
+        __shared__ u64 s_red[4];
+        u64 part_sum = 0;
+        for (int i = tid; i < c.nchunks; i += kBlock) part_sum += c.chunk_sum[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part_sum += __shfl_down(part_sum, o, 64);
+        if (lane == 0) s_red[tid >> 6] = part_sum;
+        __syncthreads();
+        if (tid == 0) {
+            const u64 nf = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+            hdr[H_T] = nf;
+            mb_publish_f(mb, seq, nf);
+        }
+    }
+    if (!c.scratch || c.capv <= 0) return;
+    const int r = blockIdx.x % kRegions, part = c.part0 + blockIdx.x / kRegions, nparts = c.nparts;
+    const int64_t rows = (int64_t)min(s_cur[r], (u64)c.store_rows);
+    const int64_t dst0 = (int64_t)s_pre[r] * 3;
+    const int64_t n = min(rows * 3, c.capv * 3 - dst0);  // floats to move (<= 0: nothing fits)
+    if (n <= 0) return;
+    const float* __restrict__ src = c.scratch + (size_t)r * c.store_rows * 3;
+    float* __restrict__ dst = c.verts + dst0;
+    const int64_t head = min(n, (int64_t)((4 - (dst0 & 3)) & 3));  // floats before the first 16-byte boundary of dst
+    const int64_t nvec = (n - head) >> 2;
+    const int64_t tail0 = head + nvec * 4;
+    if (part == 0 && tid < 8) {
+        if (tid < head) dst[tid] = src[tid];
+        if (tid >= 4 && tail0 + (tid - 4) < n) dst[tail0 + (tid - 4)] = src[tail0 + (tid - 4)];
+    }
+    const F4U* __restrict__ s4 = (const F4U*)(src + head);
+    F4A* __restrict__ d4 = (F4A*)(dst + head);
+    const int64_t stride = (int64_t)nparts * kBlock;
+    int64_t i = (int64_t)part * kBlock + tid;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {  // four loads in flight per lane
+        const F4U a0 = __builtin_nontemporal_load(s4 + i), a1 = __builtin_nontemporal_load(s4 + i + stride);
+        const F4U a2 = __builtin_nontemporal_load(s4 + i + 2 * stride), a3 = __builtin_nontemporal_load(s4 + i + 3 * stride);
+        // streaming stores: the copy is never read again by this call, and keeping its 63 MB out of the caches lets
+        // the NEXT call's streaming kernel start on a clean L2 / Infinity Cache (measured: -7 us on k_fused in a
+        // back-to-back call stream).  The same policy on the 12-byte face stores costs far more than it saves.
+        __builtin_nontemporal_store(a0, d4 + i);
+        __builtin_nontemporal_store(a1, d4 + i + stride);
+        __builtin_nontemporal_store(a2, d4 + i + 2 * stride);
+        __builtin_nontemporal_store(a3, d4 + i + 3 * stride);
+    }
+    for (; i < nvec; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(s4 + i), d4 + i);
+}
+
 // Triangle counts.  A block owns a CHUNK = one tile column over `xw` consecutive planes and walks it along x: every
 // sign word is loaded once per chunk (plane x+1 of one step is plane x of the next; all loads of a sub-batch of PB
 // planes are issued together).  Lane = unit: the 8 corner signs of the unit's 64 cells are 8 words (the four column
@@ -461,10 +554,15 @@ __device__ inline void wave_lds_sync() {  // orders one wave's LDS traffic acros
 #endif
 template <int PB>
 __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restrict__ bits, Dims d, int64_t tpp, int xw,
-                                                            u32* __restrict__ chunk_sum, u32* __restrict__ wave_off) {
+                                                            u32* __restrict__ chunk_sum, u32* __restrict__ wave_off,
+                                                            CompactArgs cp, u64* __restrict__ hdr) {
+    if ((int)blockIdx.x < cp.nblocks) {  // the launch's first blocks move vertices (uniform per block)
+        compact_block(cp, hdr, nullptr, 0);
+        return;
+    }
     __shared__ u32 s_part[PB][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t chunk = blockIdx.x;
+    const int64_t chunk = (int64_t)blockIdx.x - cp.nblocks;
     const int64_t xc = chunk / tpp, tile = chunk - xc * tpp;
     const int64_t x_begin = xc * xw, x_end = min(x_begin + xw, d.rx - 1);  // cell layers [x_begin, x_end)
     const int64_t p = tile * kBlock + tid;
@@ -570,97 +668,6 @@ __global__ void __launch_bounds__(kBlock) k_export_plane_records(const uint2* __
         if (reg < (u32)kRegions) r.x = (r.x & 0x3ffffffu) + (u32)hdr[H_PREFIX + reg];
     }
     out[i] = r;
-}
-
-// Compaction of the streaming kernel's 32 vertex regions, riding in the face kernel's launch: its first
-// `nblocks` blocks copy while the other blocks emit faces (a bandwidth-bound and an ALU-bound job side by side,
-// one stream, no events).  Block j serves region j % 32, slice j / 32.  16-byte vectors aligned on the
-// destination; the source is read with 4-byte-aligned 16-byte loads.  Block 0 also finishes the header: V, F, the
-// overflow flag, the region prefixes, the record form flag, and publishes V and F to the host.
-struct CompactArgs {
-    const float* scratch;  // null: nothing to copy (counting call), the header is still finished
-    float* verts;
-    int64_t capv;
-    u32 store_rows, region_rows;
-    int nblocks;           // multiple of kRegions (0: no compaction blocks in this launch)
-    const u32* chunk_sum;  // block 0 adds the chunk sums up to F
-    int nchunks;
-    const u64* cursors;    // the call's cursor block
-};
-typedef float F4U __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access at 4-byte alignment
-typedef float F4A __attribute__((ext_vector_type(4)));
-__device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr, u64* mb, u64 seq) {
-    __shared__ u64 s_cur[kRegions], s_pre[kRegions];
-    const int tid = threadIdx.x, lane = tid & 63;
-    if (tid < 64) {
-        const u64 cur = lane < kRegions ? c.cursors[lane * kCursorStride] : 0ull;
-        u64 inc = cur;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const u64 tt = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += tt;
-        }
-        if (lane < kRegions) {
-            s_cur[lane] = cur;
-            s_pre[lane] = inc - cur;
-        }
-        if (blockIdx.x == 0) {
-            const u64 over = __ballot(cur > (u64)(c.scratch ? c.store_rows : c.region_rows));
-            if (lane < kRegions) hdr[H_PREFIX + lane] = inc - cur;
-            if (lane == kRegions - 1) {
-                hdr[H_V] = inc;
-                hdr[H_FLAGS] = over ? 1ull : 0ull;
-                hdr[H_RECFORM] = 1ull;
-                mb_publish_v(mb, seq, inc, over ? 1ull : 0ull);
-            }
-        }
-    }
-    __syncthreads();
-    if (blockIdx.x == 0) {
-        __shared__ u64 s_red[4];
-        u64 part_sum = 0;
-        for (int i = tid; i < c.nchunks; i += kBlock) part_sum += c.chunk_sum[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part_sum += __shfl_down(part_sum, o, 64);
-        if (lane == 0) s_red[tid >> 6] = part_sum;
-        __syncthreads();
-        if (tid == 0) {
-            const u64 nf = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-            hdr[H_T] = nf;
-            mb_publish_f(mb, seq, nf);
-        }
-    }
-    if (!c.scratch || c.capv <= 0) return;
-    const int r = blockIdx.x % kRegions, part = blockIdx.x / kRegions, nparts = c.nblocks / kRegions;
-    const int64_t rows = (int64_t)min(s_cur[r], (u64)c.store_rows);
-    const int64_t dst0 = (int64_t)s_pre[r] * 3;
-    const int64_t n = min(rows * 3, c.capv * 3 - dst0);  // floats to move (<= 0: nothing fits)
-    if (n <= 0) return;
-    const float* __restrict__ src = c.scratch + (size_t)r * c.store_rows * 3;
-    float* __restrict__ dst = c.verts + dst0;
-    const int64_t head = min(n, (int64_t)((4 - (dst0 & 3)) & 3));  // floats before the first 16-byte boundary of dst
-    const int64_t nvec = (n - head) >> 2;
-    const int64_t tail0 = head + nvec * 4;
-    if (part == 0 && tid < 8) {
-        if (tid < head) dst[tid] = src[tid];
-        if (tid >= 4 && tail0 + (tid - 4) < n) dst[tail0 + (tid - 4)] = src[tail0 + (tid - 4)];
-    }
-    const F4U* __restrict__ s4 = (const F4U*)(src + head);
-    F4A* __restrict__ d4 = (F4A*)(dst + head);
-    const int64_t stride = (int64_t)nparts * kBlock;
-    int64_t i = (int64_t)part * kBlock + tid;
-    for (; i + 3 * stride < nvec; i += 4 * stride) {  // four loads in flight per lane
-        const F4U a0 = __builtin_nontemporal_load(s4 + i), a1 = __builtin_nontemporal_load(s4 + i + stride);
-        const F4U a2 = __builtin_nontemporal_load(s4 + i + 2 * stride), a3 = __builtin_nontemporal_load(s4 + i + 3 * stride);
-        // streaming stores: the copy is never read again by this call, and keeping its 63 MB out of the caches lets
-        // the NEXT call's streaming kernel start on a clean L2 / Infinity Cache (measured: -7 us on k_fused in a
-        // back-to-back call stream).  The same policy on the 12-byte face stores costs far more than it saves.
-        __builtin_nontemporal_store(a0, d4 + i);
-        __builtin_nontemporal_store(a1, d4 + i + stride);
-        __builtin_nontemporal_store(a2, d4 + i + 2 * stride);
-        __builtin_nontemporal_store(a3, d4 + i + 3 * stride);
-    }
-    for (; i < nvec; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(s4 + i), d4 + i);
 }
 
 // Faces from sign words + vertex-id records.  One block = one tile; after ONE block barrier (the staging below) its
@@ -1129,8 +1136,9 @@ int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3
     }
     if (w.nchunks > 0) {
         StageTimer tm(ST_FACES_COUNT, st);
+        const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr};
         hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)w.nchunks), dim3(kBlock), 0, st, bits, d, w.tpp, w.xw, csum,
-                           woff);
+                           woff, none, hdr);
     }
     {
         StageTimer tm(ST_SCAN_F, st);
@@ -1165,7 +1173,7 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
         const FaceArgs a{2, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
                          slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw,
                          (const u32*)(ws + w.chunk_sum), (const u32*)(ws + w.wave_off), nullptr, nullptr, 0};
-        const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr};
+        const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr};
         if (d.ncz <= 32)
             hipLaunchKernelGGL(k_faces<32>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, none, hdr, faces, capf);
         else
@@ -1292,18 +1300,23 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     const bool faces_here = w.nb_f > 0 && capf > 0 && !halo;
     u64 seq = 0;
     u64* mb = mailbox_open(ws, &seq);
+    // the copy of the vertex regions is split over the two launches: `early` of `nparts` slices of every region ride
+    // with the counting kernel (VALU-bound, HBM idle), the rest with k_faces
+    const bool copy = scratch && capv > 0;
+    const int nparts = copy ? std::max(1, env_int("P3D_COMPACT_BLOCKS", 256) / kRegions) : 1;
+    const int early = (copy && w.nchunks > 0) ? std::min(nparts - 1, env_int("P3D_COMPACT_EARLY", 3)) : 0;
     if (w.nchunks > 0) {
         StageTimer tm(ST_FACES_COUNT, st);
-        hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)w.nchunks), dim3(kBlock), 0, st, bits, d, w.tpp, w.xw, csum,
-                           woff);
+        const CompactArgs cpe{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, early * kRegions, 0, nparts, 0,
+                              csum, (int)w.nchunks, cursors};
+        hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)(w.nchunks + cpe.nblocks)), dim3(kBlock), 0, st, bits,
+                           d, w.tpp, w.xw, csum, woff, cpe, hdr);
     }
-    const bool copy = scratch && capv > 0;
     const FaceArgs a{1, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
                      slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw,
                      csum, woff, cursors, mb, seq};
-    const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows,
-                         copy ? std::max(1, env_int("P3D_COMPACT_BLOCKS", 256) / kRegions) * kRegions : kRegions,
-                         csum, (int)w.nchunks, cursors};
+    const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, (nparts - early) * kRegions, early,
+                         nparts, 1, csum, (int)w.nchunks, cursors};
     StageTimer tm(ST_EMIT_FACES, st);
     const dim3 fgrid((u32)((faces_here ? w.nb_f : 0) + cp.nblocks));
     if (d.ncz <= 32)
