@@ -10,7 +10,7 @@ from ._build import capi_path, pybind_path
 if not capi_path().exists() or not pybind_path().exists():
     raise ImportError(
         "primitive3d_amd native libraries are not built "
-        f"({capi_path().name}, {pybind_path().name}); run `python -m primitive3d_amd._build` "
+        f"({capi_path().name}, {pybind_path().name}); run `python primitive3d_amd/_build.py` "
         "or `__graft_entry__.build()`. There is no fallback path.")
 
 from . import libPrim3D  # noqa: E402  (pybind adapter over the C ABI)

@@ -35,7 +35,7 @@ def lib():
     if _LIB is None:
         path = capi_path()
         if not path.exists():
-            raise ImportError(f"{path} is missing: build it with `python -m primitive3d_amd._build` "
+            raise ImportError(f"{path} is missing: build it with `python primitive3d_amd/_build.py` "
                               "(or __graft_entry__.build()); there is no CPU fallback")
         L = ctypes.CDLL(str(path))
         L.p3d_mc_abi_version.restype = c_int

@@ -12,13 +12,17 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # test modules import the package at collection time and the package refuses to import without its native
+    # artefacts: (re)build them first -- a no-op when they are up to date (they travel with the repo snapshot)
+    import __graft_entry__
+    __graft_entry__.load_build_module().build_all()
 
 
 @pytest.fixture(scope="session")
 def built():
     """Build (if stale) and import the native artefacts; every test that touches them depends on this."""
-    from primitive3d_amd import _build
-    _build.build_all()
+    import __graft_entry__
+    __graft_entry__.load_build_module().build_all()
     import primitive3d_amd
     return primitive3d_amd
 
