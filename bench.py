@@ -61,6 +61,11 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.load_build_module().build_all()  # no-op when the in-tree libraries are up to date
+    if world > 1:
+        dist.barrier()
     import primitive3d_amd as p3d
     from primitive3d_amd import capi
     from primitive3d_amd.fields import perlin_grid
