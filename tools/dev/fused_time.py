@@ -20,9 +20,3 @@ for i in range(8):
     if i >= 3:
         for k, t in st.items(): acc[k] = acc.get(k, 0) + t / 5
 print(os.environ.get("P3D_CAPI_LIB", "default"), "V", nv, "F", nf, {k: round(t * 1e3, 1) for k, t in acc.items()}, "us")
-if os.environ.get("STAMPS"):
-    h = ws[:8192].cpu().numpy().view("uint64")
-    seg = h[640:644].astype(float)
-    names = ["make_words(+load wait)", "bookkeeping+bits+atomic issue+misc", "vertex work (vinfo, batches, stores, rec)", "prefetch issue + store_plane + loop"]
-    tot = seg.sum()
-    print("stamps (share of wave cycles):", {n: f"{100*v/tot:.1f}%" for n, v in zip(names, seg)}, "cycles/wave-step", round(tot / 88064))
