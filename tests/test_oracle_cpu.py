@@ -114,3 +114,17 @@ def test_strict_greater_and_nan_are_outside():
     assert oracle_count(g, 0.0) == (0, 0)
     g[0, 0, 0] = np.nan
     assert oracle_count(g, -1.0)[0] == 3  # NaN > t is false: the NaN corner is the only outside sample
+
+
+def test_bitsliced_count_network_is_current(tmp_path, monkeypatch):
+    """csrc/tri_count_bitsliced.inc is what tools/gen_tri_count_bitsliced.py generates from the committed case table
+    (the generator also verifies the network against the table for all 256 masks)."""
+    import importlib.util
+    root = Path(__file__).resolve().parents[1]
+    spec = importlib.util.spec_from_file_location("gen_bs", root / "tools" / "gen_tri_count_bitsliced.py")
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    out = tmp_path / "tri_count_bitsliced.inc"
+    monkeypatch.setattr(gen, "OUT", out)
+    assert gen.main() == 0
+    assert out.read_text() == (root / "primitive3d_amd" / "csrc" / "tri_count_bitsliced.inc").read_text()
