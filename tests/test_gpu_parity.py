@@ -187,3 +187,12 @@ def test_counts_without_the_mailbox(gpu):
     g, t, _, _ = small_cases()["noise_33x17x200"]
     nv, nf = oracle_count(g, t)
     assert out.stdout.split() == [str(nv), str(nf), str(nv), str(nf)]
+
+
+@pytest.mark.parametrize("early", ["0", "1", "7"])
+def test_vertex_copy_split_between_the_two_face_launches(gpu, monkeypatch, early):
+    """P3D_COMPACT_EARLY slices of every vertex region are copied by blocks riding with the counting kernel, the
+    rest by blocks riding with k_faces: any split gives the same mesh."""
+    monkeypatch.setenv("P3D_COMPACT_EARLY", early)
+    g, thresh, lower, upper = small_cases()["perlin_40x24x96_thr"]
+    _assert_same_mesh(_hip_extract_fused(gpu, g, thresh, lower, upper), oracle_extract(g, thresh, lower, upper))
