@@ -55,17 +55,22 @@ typedef struct p3d_mc_slab {
     int32_t part;            /* p3d_mc_extract_fused only.  0: the whole slab in one call.
                                 1: stream planes [0, split_plane) and return (no finalize, no face pass) -- lets
                                    the interior run while the halo plane is still in flight;
-                                2: continue with planes [split_plane, rx), then finalize and count faces.
-                                Parts 1 and 2 must be given the same buffers. */
+                                2: continue with planes [split_plane, rx), then finalize and count faces;
+                                3: stream planes [split_plane, rx) (all of them if split_plane is 0) and write V and the
+                                   id prefixes into the workspace header, but do not finalize: collectives that
+                                   only need those (all-gather of V = the first int64 of ws, export of the first
+                                   plane's records) can be enqueued now and travel while part 4 runs;
+                                4: finalize only (face count, vertex compaction, totals to the host).
+                                All parts of one extraction must be given the same buffers and stream. */
     int64_t vertex_id_base;      /* added to every locally owned vertex id written into faces */
     int64_t halo_vertex_id_base; /* added to the imported records of the halo plane */
     int64_t x_origin;            /* global axis-0 index of local plane 0: vertex x = float(x_origin + x) + dt */
     int64_t split_plane;         /* see `part` */
-    const int64_t* rank_counts;  /* optional DEVICE pointer to the all-gathered {vertices, faces} pairs of all ranks
-                                    ([world][2] int64).  When set, the face kernel derives the two bases itself
-                                    (vertex_id_base = sum of the vertex counts of ranks < rank, halo base = that +
-                                    this rank's count) and ignores the two fields above: the host never waits
-                                    for the other ranks' counts, the all-gather result stays on the device. */
+    const int64_t* rank_counts;  /* optional DEVICE pointer to the all-gathered vertex counts of all ranks ([world]
+                                    int64).  When set, the face kernel derives the two bases itself
+                                    (vertex_id_base = sum of the counts of ranks < rank, halo base = that + this
+                                    rank's count) and ignores the two fields above: the host never waits for the
+                                    other ranks' counts, the all-gather result stays on the device. */
     int32_t rank;                /* index of this rank in rank_counts */
 } p3d_mc_slab;
 

@@ -426,7 +426,7 @@ struct FaceArgs {
                 // 2 if hdr[H_RECFORM] says so, region bases from hdr[H_PREFIX] (a later p3d_mc_emit)
     int halo_last;
     int64_t vid_base, halo_vid_base;
-    const int64_t* rank_counts;  // optional: all-gathered {V, F} of all ranks on the device; bases are derived from it
+    const int64_t* rank_counts;  // optional: all-gathered V of all ranks on the device; the id bases are derived from it
     int rank;
     int64_t tpp;           // tiles per plane
     int xw;                // planes per chunk (face_chunk_planes)
@@ -654,6 +654,28 @@ __global__ void __launch_bounds__(kBlock) k_face_total(const u32* __restrict__ c
     }
 }
 
+// V, the overflow flag and the region prefixes as soon as the streaming kernel is done (one wave).  The multi-GPU
+// path wants them before the face count: the all-gather of V and the export of the first plane's records can then
+// travel while the counting and compaction kernels run.  (The finishing block of the k_faces launch writes the
+// same values again and reports to the host.)
+__global__ void k_early_header(u64* __restrict__ hdr, const u64* __restrict__ cursors, u32 rows_per_region) {
+    const int lane = threadIdx.x;
+    const u64 cur = lane < kRegions ? cursors[lane * kCursorStride] : 0ull;
+    u64 inc = cur;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u64 tt = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += tt;
+    }
+    const u64 over = __ballot(cur > (u64)rows_per_region);
+    if (lane < kRegions) hdr[H_PREFIX + lane] = inc - cur;
+    if (lane == kRegions - 1) {
+        hdr[H_V] = inc;
+        hdr[H_FLAGS] = over ? 1ull : 0ull;
+        hdr[H_RECFORM] = 1ull;
+    }
+}
+
 // Dense copy of one plane's vertex-id records (the multi-GPU path ships the first plane to the previous rank, whose
 // halo plane it is).  After a one-pass call rec[] still holds region-form ids: translated here with the region
 // prefixes of the header.
@@ -802,9 +824,9 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     u32 b0 = (u32)a.vid_base, bhalo = (u32)a.halo_vid_base;
     if (a.rank_counts) {  // uniform: a handful of scalar loads
         int64_t acc = 0;
-        for (int r = 0; r < a.rank; ++r) acc += a.rank_counts[2 * r];
+        for (int r = 0; r < a.rank; ++r) acc += a.rank_counts[r];
         b0 = (u32)acc;
-        bhalo = (u32)(acc + a.rank_counts[2 * a.rank]);
+        bhalo = (u32)(acc + a.rank_counts[a.rank]);
     }
     const u32 bh = xhalo ? bhalo : b0;
     unsigned short* const cells = s_cells[wave];
@@ -1274,21 +1296,26 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     const u32 region_rows = 1u << 26;
     const u32 store_rows = scratch ? (u32)std::min<int64_t>(scratch_rows / kRegions, (int64_t)region_rows) : 0u;
     const int part = slab ? slab->part : 0;
+    // parts (p3d_mc_slab.part): 0 everything; 1 planes [0, split) only; 2 planes [split, rx) + finalize;
+    // 3 planes [split, rx) + early header, no finalize; 4 finalize only
     int x_lo = 0, x_hi = (int)d.rx;
     if (part == 1) x_hi = (int)slab->split_plane;
-    if (part == 2) x_lo = (int)slab->split_plane;
+    if (part == 2 || part == 3) x_lo = (int)slab->split_plane;
     u64 *cursors = nullptr, *zero_next = nullptr;
-    if (int rc = cursor_block_for(st, part != 2, &cursors, &zero_next)) return rc;
-    {
+    const bool new_block = part == 0 || part == 1 || (part == 3 && slab->split_plane == 0);
+    if (int rc = cursor_block_for(st, new_block, &cursors, &zero_next)) return rc;
+    if (part != 4) {
         const int stage = part == 1 ? ST_FUSED_INTERIOR : ST_FUSED;
         const bool timed = g_prof_mode != 0;
         if (timed) g_ev_used[stage] = true;
-        if (part == 0) g_ev_used[ST_FUSED_INTERIOR] = false;
+        if (new_block && part != 1) g_ev_used[ST_FUSED_INTERIOR] = false;
         const int64_t xo = slab ? slab->x_origin : 0;
         dispatch_fused<T>(grid, d, thresh, halo, t, xo, bits, rec, cursors, zero_next, scratch, region_rows, store_rows, x_lo, x_hi,
                           timed ? g_ev[stage][0] : nullptr, timed ? g_ev[stage][1] : nullptr, st);
     }
-    if (part == 1) {  // the second part finalizes
+    if (part == 3)
+        hipLaunchKernelGGL(k_early_header, dim3(1), dim3(64), 0, st, hdr, cursors, scratch ? store_rows : region_rows);
+    if (part == 1 || part == 3) {  // a later call finalizes
         HIP_TRY(hipGetLastError());
         return P3D_OK;
     }
@@ -1403,8 +1430,11 @@ int p3d_mc_extract_fused(const void* grid, int dtype, int64_t rx, int64_t ry, in
     if (cap_vertices > 0 && (!vertex_scratch || scratch_rows < kRegions))
         return fail(P3D_EINVAL, "vertex output needs a scratch buffer of at least 32 rows%s");
     if (int rc = check_dims(rx, ry, rz)) return rc;
-    if (slab && slab->part != 0 && (slab->part < 0 || slab->part > 2 || slab->split_plane < 1 || slab->split_plane >= rx))
-        return fail(P3D_EINVAL, "bad slab part / split_plane%s");
+    if (slab && (slab->part < 0 || slab->part > 4)) return fail(P3D_EINVAL, "bad slab part%s");
+    if (slab && (slab->part == 1 || slab->part == 2) && (slab->split_plane < 1 || slab->split_plane >= rx))
+        return fail(P3D_EINVAL, "bad split_plane%s");
+    if (slab && slab->part == 3 && (slab->split_plane < 0 || slab->split_plane >= rx))
+        return fail(P3D_EINVAL, "bad split_plane%s");
     const Dims d = make_dims(rx, ry, rz);
     const Ws w = make_ws(d);
     const Xform t = make_xform(d, lower, upper, full_res);

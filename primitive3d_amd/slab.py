@@ -66,13 +66,27 @@ class HipBackend:
         self.capi.extract_fused_raw(grid, thresh, lower, upper, self._ws, self._verts, None, slab=self._mk(1, split),
                                     full_res=full_res, scratch=self._scratch)
 
-    def count_and_vertices(self, grid, thresh, lower, upper, full_res, x_origin, halo):
+    def stream_rest(self, grid, thresh, lower, upper, full_res, x_origin, halo):
+        """Stream the planes not yet streamed and leave V and the id prefixes in the workspace header (no finalize):
+        what the collectives need is on the device now, so they can be enqueued and travel during `finalize`."""
         c = self.capi
         split = getattr(self, "_split", 0)
         if not split:
             self._prepare(grid, x_origin, halo)
-        ws, verts = self._ws, self._verts
-        c.extract_fused_raw(grid, thresh, lower, upper, ws, verts, None, slab=self._mk(2 if split else 0, split),
+        c.extract_fused_raw(grid, thresh, lower, upper, self._ws, self._verts, None, slab=self._mk(3, split),
+                            full_res=full_res, scratch=self._scratch)
+        self._state = (grid, thresh, lower, upper, full_res, self._ws, None)
+
+    def header_vertex_count(self):
+        """This rank's vertex count as a device tensor (the first int64 of the workspace): all-gather input."""
+        return self._ws[:8].view(torch.int64)
+
+    def finalize(self):
+        """Face count + vertex compaction, totals to the host."""
+        c = self.capi
+        grid, thresh, lower, upper, full_res, ws, _ = self._state
+        verts = self._verts
+        c.extract_fused_raw(grid, thresh, lower, upper, ws, verts, None, slab=self._mk(4, getattr(self, "_split", 0)),
                             full_res=full_res, scratch=self._scratch)
         self._split = 0
         self._slab = self._mk()
@@ -84,6 +98,10 @@ class HipBackend:
         self._state = (grid, thresh, lower, upper, full_res, ws, nf)
         self._scratch = None
         return nv, nf, verts[:nv]
+
+    def count_and_vertices(self, grid, thresh, lower, upper, full_res, x_origin, halo):
+        self.stream_rest(grid, thresh, lower, upper, full_res, x_origin, halo)
+        return self.finalize()
 
     def _plane_view(self, plane):
         grid, ws = self._state[0], self._state[5]
@@ -108,8 +126,8 @@ class HipBackend:
         return faces
 
     def faces_from_rank_counts(self, rank_counts, rank):
-        """Same, with the id bases derived ON THE DEVICE from the all-gathered [world, 2] int64 counts: the host does
-        not wait for the other ranks (include/p3d_mc.h: p3d_mc_slab.rank_counts)."""
+        """Same, with the id bases derived ON THE DEVICE from the all-gathered [world] int64 vertex counts: the host
+        does not wait for the other ranks (include/p3d_mc.h: p3d_mc_slab.rank_counts)."""
         grid, thresh, lower, upper, full_res, ws, nf = self._state
         slab = self._mk(0, 0, 0, 0, rank_counts, rank)
         faces = torch.empty((nf, 3), dtype=torch.int32, device=self.device)
@@ -123,23 +141,18 @@ class HipBackend:
 class SlabResult:
     """vertices: [V_r, 3] f32, already in bounding-box coordinates of the FULL grid
     faces:    [F_r, 3] i32, GLOBAL vertex ids (vertices of all ranks concatenated in rank order)
-    counts / vertex_base: (V, F) of every rank and this rank's first global vertex id; when the extraction kept the
-    all-gathered counts on the device they are copied to the host on first access (a synchronisation)."""
+    vertex_base: this rank's first global vertex id; when the extraction kept the all-gathered vertex counts on the
+    device it is computed from them on first access (a device-to-host copy, i.e. a synchronisation).
+    counts: (V, F) of every rank -- host path only."""
 
     def __init__(self, vertices, faces, vertex_base=None, counts=None, rank=None, rank_counts=None):
         self.vertices, self.faces = vertices, faces
-        self._base, self._counts, self._rank, self._rank_counts = vertex_base, counts, rank, rank_counts
-
-    @property
-    def counts(self) -> List[Tuple[int, int]]:
-        if self._counts is None:
-            self._counts = [(int(c[0]), int(c[1])) for c in self._rank_counts.view(-1, 2).cpu()]
-        return self._counts
+        self._base, self.counts, self._rank, self._rank_counts = vertex_base, counts, rank, rank_counts
 
     @property
     def vertex_base(self) -> int:
         if self._base is None:
-            self._base = sum(c[0] for c in self.counts[:self._rank])
+            self._base = int(self._rank_counts[:self._rank].sum()) if self._rank else 0
         return self._base
 
     def __iter__(self):  # (vertices, faces) unpacking like the single-GPU call
@@ -223,17 +236,23 @@ class SlabExtractor:
         self.phase_interior(thresh, lower, upper)
         for w in works:
             w.wait()
+        if hasattr(self.backend, "faces_from_rank_counts"):
+            # device path: V and the id prefixes are in the workspace header as soon as the slab is streamed, so the
+            # all-gather of V and the record exchange are enqueued BEFORE the face count / vertex compaction and
+            # travel while those run; the other ranks' counts never visit the host (the face kernel derives its id
+            # bases from the gathered tensor)
+            be = self.backend
+            be.stream_rest(self.grid, float(thresh), list(lower), list(upper), self.shape, self.x0, self.has_halo)
+            rank_counts = torch.empty(self.world, dtype=torch.int64, device=self.grid.device)
+            dist.all_gather_into_tensor(rank_counts, be.header_vertex_count())
+            rec_works = shift_to_prev(self.records_send_buffer(), self.records_recv_buffer())
+            self._nv, self._nf, self._verts = be.finalize()
+            for w in rec_works:
+                w.wait()
+            faces = be.faces_from_rank_counts(rank_counts, self.rank)
+            return SlabResult(self._verts, faces, rank=self.rank, rank_counts=rank_counts)
         nv, nf = self.phase_extract(thresh, lower, upper)
         mine = torch.tensor([nv, nf], dtype=torch.int64, device=self.grid.device)
-        if hasattr(self.backend, "faces_from_rank_counts"):
-            # the counts of the other ranks never visit the host: the face kernel derives its id bases from the
-            # all-gathered tensor, and both collectives are only stream-ordered before it
-            rank_counts = torch.empty(2 * self.world, dtype=torch.int64, device=self.grid.device)
-            dist.all_gather_into_tensor(rank_counts, mine)
-            for w in shift_to_prev(self.records_send_buffer(), self.records_recv_buffer()):
-                w.wait()
-            faces = self.backend.faces_from_rank_counts(rank_counts, self.rank)
-            return SlabResult(self._verts, faces, rank=self.rank, rank_counts=rank_counts)
         allc = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(allc, mine)
         counts = [(int(c[0]), int(c[1])) for c in torch.stack(allc).cpu()]

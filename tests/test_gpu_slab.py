@@ -33,7 +33,7 @@ def test_slabs_merge_to_the_whole_grid_mesh(gpu, world, device_bases):
         exs[r].records_recv_buffer().copy_(exs[r + 1].records_send_buffer())
     if device_bases:  # the id bases come from the all-gathered counts ON THE DEVICE (p3d_mc_slab.rank_counts)
         from primitive3d_amd.slab import SlabResult
-        rank_counts = torch.tensor(counts, dtype=torch.int64, device=gpu).reshape(-1)
+        rank_counts = torch.tensor([c[0] for c in counts], dtype=torch.int64, device=gpu)
         res = [SlabResult(e._verts, e.backend.faces_from_rank_counts(rank_counts, e.rank), rank=e.rank,
                           rank_counts=rank_counts) for e in exs]
     else:
@@ -52,6 +52,7 @@ def test_slabs_merge_to_the_whole_grid_mesh(gpu, world, device_bases):
         allv.append(out.vertices.cpu().numpy())
         allf.append(out.faces.cpu().numpy())
         assert out.vertex_base == sum(c[0] for c in counts[:e.rank])
+        assert int(e.backend.header_vertex_count()[0]) == counts[e.rank][0]  # what the all-gather would read
     hip = (np.concatenate(allv), np.concatenate(allf), np.concatenate(allk))
     _assert_same_mesh(hip, oracle_extract(g, thresh, lower, upper))
 

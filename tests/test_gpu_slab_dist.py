@@ -1,0 +1,65 @@
+"""The multi-GPU call itself (SlabExtractor.extract with the HIP backend: collectives enqueued before the finalize
+kernels, id bases derived on the device from the all-gathered vertex counts) run by TWO processes that share the one
+GPU of the test box, gloo standing in for RCCL as transport.  The merged mesh must equal the oracle's mesh of the whole
+grid."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+from oracle import canonical_mesh, oracle_extract  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, out_dir, shape, thresh, lower, upper):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from primitive3d_amd import capi
+    from primitive3d_amd.fields import perlin_grid
+    from primitive3d_amd.slab import SlabExtractor
+    from tests.ws_keys import vertex_keys_from_workspace
+    dev = torch.device("cuda", 0)
+    ex = SlabExtractor(shape, rank, world, dev)
+    # (generated on the CPU like the oracle's input: the device generator may differ in the last bit)
+    ex.fill_local(lambda x0, x1: perlin_grid(shape, period=12, seed=5, x0=x0, x1=x1).to(dev))
+    for _ in range(2):  # the second call reuses the size hints and the cursor ring
+        res = ex.extract(thresh, lower, upper)
+    torch.cuda.synchronize()
+    lshape = tuple(ex.grid.shape)
+    k = vertex_keys_from_workspace(ex.backend._ws.cpu().numpy(), lshape, res.vertices.shape[0],
+                                   capi.debug_layout(*lshape), halo_last_plane=ex.has_halo)
+    ry, rz = shape[1], shape[2]
+    gk = (k // 3 + ex.x0 * ry * rz) * 3 + k % 3
+    np.savez(Path(out_dir) / f"r{rank}.npz", v=res.vertices.cpu().numpy(), f=res.faces.cpu().numpy(), k=gk,
+             base=res.vertex_base)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_extract_on_one_gpu(tmp_path, gpu, world):
+    from primitive3d_amd.fields import perlin_grid
+    shape, thresh, lower, upper = (61, 21, 150), 0.02, [0.5, -1.0, 2.0], [3.0, 4.0, 9.0]
+    port = 29600 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, str(tmp_path), shape, thresh, lower, upper), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    assert [int(p["base"]) for p in parts] == list(np.cumsum([0] + [len(p["v"]) for p in parts[:-1]]))
+    hip = (np.concatenate([p["v"] for p in parts]), np.concatenate([p["f"] for p in parts]),
+           np.concatenate([p["k"] for p in parts]))
+    g = perlin_grid(shape, period=12, seed=5).numpy()
+    hk, hv, hf = canonical_mesh(*hip)
+    rk, rv, rf = canonical_mesh(*oracle_extract(g, thresh, lower, upper))
+    assert hk.shape == rk.shape and hf.shape == rf.shape, (hk.shape, rk.shape, hf.shape, rf.shape)
+    assert np.array_equal(hk, rk), "vertex edge keys differ"
+    assert np.array_equal(hv, rv), "vertex positions differ"
+    assert np.array_equal(hf, rf), "faces differ"
