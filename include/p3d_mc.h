@@ -60,7 +60,10 @@ typedef struct p3d_mc_slab {
                                    id prefixes into the workspace header, but do not finalize: collectives that
                                    only need those (all-gather of V = the first int64 of ws, export of the first
                                    plane's records) can be enqueued now and travel while part 4 runs;
-                                4: finalize only (face count, vertex compaction, totals to the host).
+                                4: face count and the first part of the vertex compaction; V and F to the host;
+                                5: faces (with the halo plane's imported records and the id bases) and the rest of
+                                   the vertex compaction in one launch -- what parts 0/2 do for a slab without a
+                                   halo plane.  (After parts 0/2 with a halo plane p3d_mc_emit writes the faces.)
                                 All parts of one extraction must be given the same buffers and stream. */
     int64_t vertex_id_base;      /* added to every locally owned vertex id written into faces */
     int64_t halo_vertex_id_base; /* added to the imported records of the halo plane */

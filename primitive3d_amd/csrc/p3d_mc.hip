@@ -63,8 +63,8 @@ struct Ws {  // byte offsets into the workspace
 };
 
 constexpr int kBlock = 256;
-constexpr int kHdrBytes = 8192;   // [0,256) totals/flags; [4352,4608) region prefixes (the cursors themselves live in a
-                                  // library-owned ring, see cursor_block_for)
+constexpr int kHdrBytes = 8192;   // [0,256) totals/flags; [256,4352) the 32 cursors of a multi-part extraction (a whole-grid
+                                  // call uses a block of the library's ring, see cursor_block_for); [4352,4608) prefixes
 // header slots (u64)
 enum { H_V = 0, H_T = 1, H_FLAGS = 2, H_RECFORM = 3 /* 1: rec[].x still region * 2^26 + slot */,
        H_CURSORS = 32 /* u64 index */, H_PREFIX = 32 + 32 * 16 };
@@ -638,7 +638,7 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
 // F = sum of the chunk totals -> header + host mailbox (the counting call and the slab path; the one-pass call lets
 // block 0 of the k_faces launch do it)
 __global__ void __launch_bounds__(kBlock) k_face_total(const u32* __restrict__ chunk_sum, int nchunks,
-                                                       u64* __restrict__ hdr, u64* mb, u64 seq) {
+                                                       u64* __restrict__ hdr, u64* mb, u64 seq, int also_v) {
     __shared__ u64 s_red[4];
     const int tid = threadIdx.x;
     u64 part_sum = 0;
@@ -651,6 +651,7 @@ __global__ void __launch_bounds__(kBlock) k_face_total(const u32* __restrict__ c
         const u64 nf = s_red[0] + s_red[1] + s_red[2] + s_red[3];
         hdr[H_T] = nf;
         mb_publish_f(mb, seq, nf);
+        if (also_v) mb_publish_v(mb, seq, hdr[H_V], hdr[H_FLAGS]);  // (k_early_header left them in the header)
     }
 }
 
@@ -1164,7 +1165,7 @@ int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3
     }
     {
         StageTimer tm(ST_SCAN_F, st);
-        hipLaunchKernelGGL(k_face_total, dim3(1), dim3(kBlock), 0, st, csum, (int)w.nchunks, hdr, mb, seq);
+        hipLaunchKernelGGL(k_face_total, dim3(1), dim3(kBlock), 0, st, csum, (int)w.nchunks, hdr, mb, seq, 0);
     }
     HIP_TRY(hipGetLastError());
     return P3D_OK;
@@ -1297,14 +1298,23 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     const u32 store_rows = scratch ? (u32)std::min<int64_t>(scratch_rows / kRegions, (int64_t)region_rows) : 0u;
     const int part = slab ? slab->part : 0;
     // parts (p3d_mc_slab.part): 0 everything; 1 planes [0, split) only; 2 planes [split, rx) + finalize;
-    // 3 planes [split, rx) + early header, no finalize; 4 finalize only
+    // 3 planes [split, rx) + early header, no finalize; 4 face count (+ first slices of the vertex copy), totals to
+    // the host; 5 faces (+ the rest of the vertex copy)
     int x_lo = 0, x_hi = (int)d.rx;
     if (part == 1) x_hi = (int)slab->split_plane;
     if (part == 2 || part == 3) x_lo = (int)slab->split_plane;
+    // The 32 output cursors: a whole-grid call takes a pre-cleared block from the per-stream ring (no fill kernel).  An
+    // extraction made of several calls keeps them inside its own workspace header instead, cleared by its first part:
+    // other extractions may run on the same stream in between (the in-process multi-rank harness does exactly that).
     u64 *cursors = nullptr, *zero_next = nullptr;
     const bool new_block = part == 0 || part == 1 || (part == 3 && slab->split_plane == 0);
-    if (int rc = cursor_block_for(st, new_block, &cursors, &zero_next)) return rc;
-    if (part != 4) {
+    if (part == 0) {
+        if (int rc = cursor_block_for(st, true, &cursors, &zero_next)) return rc;
+    } else {
+        cursors = hdr + H_CURSORS;
+        if (new_block) HIP_TRY(hipMemsetAsync(cursors, 0, (size_t)kCursorBlockWords * sizeof(u64), st));
+    }
+    if (part < 4) {
         const int stage = part == 1 ? ST_FUSED_INTERIOR : ST_FUSED;
         const bool timed = g_prof_mode != 0;
         if (timed) g_ev_used[stage] = true;
@@ -1324,26 +1334,32 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     // prefixes); the records stay in region form and k_faces makes them dense on the fly.  Without a face buffer, or
     // with a halo plane (its records arrive later: the faces are then written by p3d_mc_emit), the launch consists of
     // those first blocks only.
-    const bool faces_here = w.nb_f > 0 && capf > 0 && !halo;
+    const bool faces_here = w.nb_f > 0 && capf > 0 && (!halo || part == 5);
     u64 seq = 0;
-    u64* mb = mailbox_open(ws, &seq);
+    u64* mb = part == 5 ? nullptr : mailbox_open(ws, &seq);
     // the copy of the vertex regions is split over the two launches: `early` of `nparts` slices of every region ride
     // with the counting kernel (VALU-bound, HBM idle), the rest with k_faces
     const bool copy = scratch && capv > 0;
     const int nparts = copy ? std::max(1, env_int("P3D_COMPACT_BLOCKS", 256) / kRegions) : 1;
     const int early = (copy && w.nchunks > 0) ? std::min(nparts - 1, env_int("P3D_COMPACT_EARLY", 3)) : 0;
-    if (w.nchunks > 0) {
+    if (w.nchunks > 0 && part != 5) {
         StageTimer tm(ST_FACES_COUNT, st);
         const CompactArgs cpe{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, early * kRegions, 0, nparts, 0,
                               csum, (int)w.nchunks, cursors};
         hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)(w.nchunks + cpe.nblocks)), dim3(kBlock), 0, st, bits,
                            d, w.tpp, w.xw, csum, woff, cpe, hdr);
     }
+    if (part == 4) {  // totals to the host now; the faces (and the rest of the vertex copy) follow in part 5
+        StageTimer tm(ST_SCAN_F, st);
+        hipLaunchKernelGGL(k_face_total, dim3(1), dim3(kBlock), 0, st, csum, (int)w.nchunks, hdr, mb, seq, 1);
+        HIP_TRY(hipGetLastError());
+        return P3D_OK;
+    }
     const FaceArgs a{1, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
                      slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw,
                      csum, woff, cursors, mb, seq};
     const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, (nparts - early) * kRegions, early,
-                         nparts, 1, csum, (int)w.nchunks, cursors};
+                         nparts, part == 5 ? 0 : 1, csum, (int)w.nchunks, cursors};
     StageTimer tm(ST_EMIT_FACES, st);
     const dim3 fgrid((u32)((faces_here ? w.nb_f : 0) + cp.nblocks));
     if (d.ncz <= 32)
@@ -1430,7 +1446,7 @@ int p3d_mc_extract_fused(const void* grid, int dtype, int64_t rx, int64_t ry, in
     if (cap_vertices > 0 && (!vertex_scratch || scratch_rows < kRegions))
         return fail(P3D_EINVAL, "vertex output needs a scratch buffer of at least 32 rows%s");
     if (int rc = check_dims(rx, ry, rz)) return rc;
-    if (slab && (slab->part < 0 || slab->part > 4)) return fail(P3D_EINVAL, "bad slab part%s");
+    if (slab && (slab->part < 0 || slab->part > 5)) return fail(P3D_EINVAL, "bad slab part%s");
     if (slab && (slab->part == 1 || slab->part == 2) && (slab->split_plane < 1 || slab->split_plane >= rx))
         return fail(P3D_EINVAL, "bad split_plane%s");
     if (slab && slab->part == 3 && (slab->split_plane < 0 || slab->split_plane >= rx))

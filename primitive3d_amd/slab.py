@@ -82,7 +82,8 @@ class HipBackend:
         return self._ws[:8].view(torch.int64)
 
     def finalize(self):
-        """Face count + vertex compaction, totals to the host."""
+        """Face count + the first slices of the vertex compaction; V and F to the host.  The vertices are complete
+        (in stream order) once the faces have been written: the rest of the copy rides in that launch."""
         c = self.capi
         grid, thresh, lower, upper, full_res, ws, _ = self._state
         verts = self._verts
@@ -91,12 +92,13 @@ class HipBackend:
         self._split = 0
         self._slab = self._mk()
         nv, nf, over = c.read_counts(ws, with_flags=True)
-        if nv > verts.shape[0] or over:  # guess too small: ids stay valid, redo only the vertex emission, exactly sized
+        self._copy_pending = not (nv > verts.shape[0] or over)
+        if not self._copy_pending:  # guess too small: ids stay valid, redo only the vertex emission, exactly sized
             verts = torch.empty((nv, 3), dtype=torch.float32, device=self.device)
             c.emit(grid, thresh, lower, upper, ws, verts, None, slab=self._slab, full_res=full_res)
+            self._scratch = None
         self._cap = nv + nv // 8 + 4096
         self._state = (grid, thresh, lower, upper, full_res, ws, nf)
-        self._scratch = None
         return nv, nf, verts[:nv]
 
     def count_and_vertices(self, grid, thresh, lower, upper, full_res, x_origin, halo):
@@ -118,21 +120,28 @@ class HipBackend:
     def halo_records_buffer(self):
         return self._plane_view(self._state[0].shape[0] - 1)
 
-    def faces(self, vertex_id_base, halo_vertex_id_base):
+    def _emit_faces(self, slab_args):
+        """slab_args -> (vb, hb, rank_counts, rank).  One launch writes the faces and finishes the vertex copy
+        (part 5); after a capacity overflow the vertices were already rewritten and only the faces remain."""
         grid, thresh, lower, upper, full_res, ws, nf = self._state
-        slab = self._mk(0, 0, vertex_id_base, halo_vertex_id_base)
         faces = torch.empty((nf, 3), dtype=torch.int32, device=self.device)
-        self.capi.emit(grid, thresh, lower, upper, ws, None, faces, slab=slab, full_res=full_res)
+        if self._copy_pending:
+            self.capi.extract_fused_raw(grid, thresh, lower, upper, ws, self._verts, faces,
+                                        slab=self._mk(5, 0, *slab_args), full_res=full_res, scratch=self._scratch)
+            self._copy_pending = False
+            self._scratch = None
+        else:
+            self.capi.emit(grid, thresh, lower, upper, ws, None, faces, slab=self._mk(0, 0, *slab_args),
+                           full_res=full_res)
         return faces
+
+    def faces(self, vertex_id_base, halo_vertex_id_base):
+        return self._emit_faces((vertex_id_base, halo_vertex_id_base, None, 0))
 
     def faces_from_rank_counts(self, rank_counts, rank):
         """Same, with the id bases derived ON THE DEVICE from the all-gathered [world] int64 vertex counts: the host
         does not wait for the other ranks (include/p3d_mc.h: p3d_mc_slab.rank_counts)."""
-        grid, thresh, lower, upper, full_res, ws, nf = self._state
-        slab = self._mk(0, 0, 0, 0, rank_counts, rank)
-        faces = torch.empty((nf, 3), dtype=torch.int32, device=self.device)
-        self.capi.emit(grid, thresh, lower, upper, ws, None, faces, slab=slab, full_res=full_res)
-        return faces
+        return self._emit_faces((0, 0, rank_counts, rank))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -231,7 +240,16 @@ class SlabExtractor:
                 ops.append(dist.P2POp(dist.irecv, recv, self.rank + 1))
             return dist.batch_isend_irecv(ops) if ops else []
 
+        # RCCL collectives are ordered after the work already enqueued on the current stream.  gloo (CPU transport, used
+        # by the tests and the single-GPU dry run) reads device tensors without that ordering: synchronise for it.
+        gloo_on_gpu = self.grid.is_cuda and dist.get_backend() == "gloo"
+
+        def pre_comm():
+            if gloo_on_gpu:
+                torch.cuda.synchronize()
+
         # the halo plane travels while the interior planes are already being streamed
+        pre_comm()
         works = shift_to_prev(self.halo_send_buffer(), self.halo_recv_buffer())
         self.phase_interior(thresh, lower, upper)
         for w in works:
@@ -244,19 +262,24 @@ class SlabExtractor:
             be = self.backend
             be.stream_rest(self.grid, float(thresh), list(lower), list(upper), self.shape, self.x0, self.has_halo)
             rank_counts = torch.empty(self.world, dtype=torch.int64, device=self.grid.device)
+            send_buf = self.records_send_buffer()  # (kept referenced until the transfer has completed)
+            pre_comm()
             dist.all_gather_into_tensor(rank_counts, be.header_vertex_count())
-            rec_works = shift_to_prev(self.records_send_buffer(), self.records_recv_buffer())
+            rec_works = shift_to_prev(send_buf, self.records_recv_buffer())
             self._nv, self._nf, self._verts = be.finalize()
             for w in rec_works:
                 w.wait()
+            del send_buf
             faces = be.faces_from_rank_counts(rank_counts, self.rank)
             return SlabResult(self._verts, faces, rank=self.rank, rank_counts=rank_counts)
         nv, nf = self.phase_extract(thresh, lower, upper)
         mine = torch.tensor([nv, nf], dtype=torch.int64, device=self.grid.device)
         allc = [torch.empty_like(mine) for _ in range(self.world)]
+        send_buf = self.records_send_buffer()
+        pre_comm()
         dist.all_gather(allc, mine)
         counts = [(int(c[0]), int(c[1])) for c in torch.stack(allc).cpu()]
-        for w in shift_to_prev(self.records_send_buffer(), self.records_recv_buffer()):
+        for w in shift_to_prev(send_buf, self.records_recv_buffer()):
             w.wait()
         return self.phase_faces(counts)
 
