@@ -81,25 +81,64 @@ class HipBackend:
         """This rank's vertex count as a device tensor (the first int64 of the workspace): all-gather input."""
         return self._ws[:8].view(torch.int64)
 
-    def finalize(self):
-        """Face count + the first slices of the vertex compaction; V and F to the host.  The vertices are complete
-        (in stream order) once the faces have been written: the rest of the copy rides in that launch."""
+    def launch_finalize(self):
+        """Part 4: face count + the first slices of the vertex compaction; V and F go to the host mailbox."""
+        grid, thresh, lower, upper, full_res, ws, _ = self._state
+        self.capi.extract_fused_raw(grid, thresh, lower, upper, ws, self._verts, None,
+                                    slab=self._mk(4, getattr(self, "_split", 0)), full_res=full_res,
+                                    scratch=self._scratch)
+        self._split = 0
+        self._slab = self._mk()
+
+    def _read_totals(self):
+        """Wait for V and F; after a vertex-capacity overflow rewrite the vertices exactly sized (ids stay valid)."""
         c = self.capi
         grid, thresh, lower, upper, full_res, ws, _ = self._state
         verts = self._verts
-        c.extract_fused_raw(grid, thresh, lower, upper, ws, verts, None, slab=self._mk(4, getattr(self, "_split", 0)),
-                            full_res=full_res, scratch=self._scratch)
-        self._split = 0
-        self._slab = self._mk()
         nv, nf, over = c.read_counts(ws, with_flags=True)
-        self._copy_pending = not (nv > verts.shape[0] or over)
-        if not self._copy_pending:  # guess too small: ids stay valid, redo only the vertex emission, exactly sized
+        overflow = nv > verts.shape[0] or over
+        if overflow:
             verts = torch.empty((nv, 3), dtype=torch.float32, device=self.device)
             c.emit(grid, thresh, lower, upper, ws, verts, None, slab=self._slab, full_res=full_res)
-            self._scratch = None
         self._cap = nv + nv // 8 + 4096
         self._state = (grid, thresh, lower, upper, full_res, ws, nf)
-        return nv, nf, verts[:nv]
+        return nv, nf, verts[:nv], overflow
+
+    def finalize(self):
+        """Host path: totals first (the caller all-gathers them on the host), faces later.  The vertices are complete
+        (in stream order) once the faces have been written: the rest of the copy rides in that launch."""
+        self.launch_finalize()
+        nv, nf, verts, overflow = self._read_totals()
+        self._copy_pending = not overflow
+        if overflow:
+            self._scratch = None
+        return nv, nf, verts
+
+    def finish_on_device(self, rank_counts, rank):
+        """Device path: the face launch is enqueued with a capacity guess from the previous call BEFORE the host has
+        seen the totals, so no host round trip sits between the counting kernel and the faces; the totals are read
+        afterwards and the buffers narrowed (exact re-emission if the guess was too small)."""
+        c = self.capi
+        grid, thresh, lower, upper, full_res, ws, _ = self._state
+        capf = getattr(self, "_capf", None)
+        if capf is None:  # first call: no guess yet
+            nv, nf, verts = self.finalize()
+            faces = self._emit_faces((0, 0, rank_counts, rank))
+        else:
+            faces = torch.empty((capf, 3), dtype=torch.int32, device=self.device)
+            c.extract_fused_raw(grid, thresh, lower, upper, ws, self._verts, faces,
+                                slab=self._mk(5, 0, 0, 0, rank_counts, rank), full_res=full_res, scratch=self._scratch)
+            nv, nf, verts, overflow = self._read_totals()
+            self._scratch = None
+            self._copy_pending = False
+            if nf > capf:
+                faces = torch.empty((nf, 3), dtype=torch.int32, device=self.device)
+                c.emit(grid, thresh, lower, upper, ws, None, faces, slab=self._mk(0, 0, 0, 0, rank_counts, rank),
+                       full_res=full_res)
+            else:
+                faces = faces[:nf] if 2 * nf >= capf else faces[:nf].clone()
+        self._capf = nf + nf // 8 + 4096
+        return nv, nf, verts, faces
 
     def count_and_vertices(self, grid, thresh, lower, upper, full_res, x_origin, halo):
         self.stream_rest(grid, thresh, lower, upper, full_res, x_origin, halo)
@@ -193,8 +232,11 @@ class SlabExtractor:
         return self.grid[self.n] if self.has_halo else None
 
     def interior_split(self) -> int:
-        """First plane of the part that needs the halo plane (0 = do not split): the last 8 local planes."""
-        return self.n - 8 if (self.has_halo and self.n >= 24 and hasattr(self.backend, "begin_interior")) else 0
+        """First plane of the part that needs the halo plane (0 = do not split): only the last cell layer reads it; the
+        last P3D_SLAB_HOLD (default 2) local planes are held back for a short second streaming launch."""
+        import os
+        hold = max(1, int(os.environ.get("P3D_SLAB_HOLD", "2")))
+        return self.n - hold if (self.has_halo and self.n >= 24 and hasattr(self.backend, "begin_interior")) else 0
 
     def phase_interior(self, thresh, lower, upper):
         """Optional: start streaming the planes that do not depend on the halo plane."""
@@ -266,11 +308,11 @@ class SlabExtractor:
             pre_comm()
             dist.all_gather_into_tensor(rank_counts, be.header_vertex_count())
             rec_works = shift_to_prev(send_buf, self.records_recv_buffer())
-            self._nv, self._nf, self._verts = be.finalize()
+            be.launch_finalize()
             for w in rec_works:
                 w.wait()
             del send_buf
-            faces = be.faces_from_rank_counts(rank_counts, self.rank)
+            self._nv, self._nf, self._verts, faces = be.finish_on_device(rank_counts, self.rank)
             return SlabResult(self._verts, faces, rank=self.rank, rank_counts=rank_counts)
         nv, nf = self.phase_extract(thresh, lower, upper)
         mine = torch.tensor([nv, nf], dtype=torch.int64, device=self.grid.device)

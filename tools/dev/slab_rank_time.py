@@ -18,8 +18,9 @@ def step():
     be = ex.backend
     be.stream_rest(ex.grid, thresh, lower, upper, ex.shape, ex.x0, ex.has_halo)
     rank_counts[0:1].copy_(be.header_vertex_count())
-    nv, nf, verts = be.finalize()
-    return verts, be.faces_from_rank_counts(rank_counts, 0)
+    be.launch_finalize()
+    nv, nf, verts, faces = be.finish_on_device(rank_counts, 0)
+    return verts, faces
 for _ in range(5): out = step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 K = 20
