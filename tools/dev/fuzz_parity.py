@@ -1,0 +1,26 @@
+"""dev: randomized parity fuzz of the one-pass and the counting call against the oracle (small random shapes)."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+import numpy as np, torch
+from oracle import oracle_extract
+from tests.test_gpu_parity import _assert_same_mesh, _hip_extract, _hip_extract_fused
+rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
+gpu = torch.device("cuda", 0)
+n_ok = 0
+for it in range(int(os.environ.get("N", "60"))):
+    rx, ry = int(rng.integers(2, 40)), int(rng.integers(2, 40))
+    rz = int(rng.choice([rng.integers(2, 70), rng.integers(60, 140), rng.integers(250, 700), rng.integers(2040, 2200)]))
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        g = rng.standard_normal((rx, ry, rz)).astype(np.float32)
+    elif kind == 1:
+        g = rng.integers(-2, 3, size=(rx, ry, rz)).astype(np.float32)
+    else:
+        x, y, z = np.meshgrid(np.arange(rx), np.arange(ry), np.arange(rz), indexing="ij")
+        g = (np.sin(x * 0.7) + np.cos(y * 0.5) + np.sin(z * 0.11) + rng.standard_normal() * 0.3).astype(np.float32)
+    thresh = float(rng.uniform(-0.5, 0.5))
+    ref = oracle_extract(g, thresh)
+    _assert_same_mesh(_hip_extract_fused(gpu, g, thresh, None, None), ref)
+    _assert_same_mesh(_hip_extract(gpu, g, thresh, None, None), ref)
+    n_ok += 1
+print("fuzz ok:", n_ok, "cases")
