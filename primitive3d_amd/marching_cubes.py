@@ -127,14 +127,32 @@ def marching_cubes_batched(density_grids, thresh: float, scale=None):
         lower, upper = [0.0, 0.0, 0.0], [shape[0], shape[1], shape[2]]
     else:
         lower, upper = scale_to_bound(scale)
-    vs, fs, cap = [], [], None
-    for b in range(density_grids.shape[0]):
-        g = density_grids[b].contiguous()
-        v, f = capi.extract_fused(g, thresh, lower, upper, cap_vertices=cap[0] if cap else None,
-                                  cap_faces=cap[1] if cap else None)
-        cap = (v.shape[0] + v.shape[0] // 8 + 4096, f.shape[0] + f.shape[0] // 8 + 4096)  # next frame's size hint
-        vs.append(v)
-        fs.append(f)
+    # software pipeline over the items: item b+1 is launched BEFORE the host reads the totals of item b (the
+    # totals come through the library's pinned mailbox), so the GPU never waits for the host between items
+    nvox = shape[0] * shape[1] * shape[2]
+    B = density_grids.shape[0]
+    vs, fs, pending = [], [], None
+    capv, capf = max(1024, nvox // 16), 2 * max(1024, nvox // 16)  # first guess; then the previous item's sizes
+    for b in range(B + 1):
+        cur = None
+        if b < B:
+            g = density_grids[b].contiguous()
+            ws = torch.empty(capi.workspace_bytes(*shape), dtype=torch.uint8, device=g.device)
+            v = torch.empty((capv, 3), dtype=torch.float32, device=g.device)
+            f = torch.empty((capf, 3), dtype=torch.int32, device=g.device)
+            capi.extract_fused_raw(g, thresh, lower, upper, ws, v, f)
+            cur = (g, ws, v, f)
+        if pending is not None:
+            g0, ws0, v0, f0 = pending
+            nv, nf, over = capi.read_counts(ws0, with_flags=True)
+            if nv > v0.shape[0] or nf > f0.shape[0] or over:  # guess too small: exact re-emission (ids stay valid)
+                v0 = torch.empty((nv, 3), dtype=torch.float32, device=g0.device)
+                f0 = torch.empty((nf, 3), dtype=torch.int32, device=g0.device)
+                capi.emit(g0, thresh, lower, upper, ws0, v0, f0)
+            vs.append(v0[:nv])
+            fs.append(f0[:nf])
+            capv, capf = nv + nv // 8 + 4096, nf + nf // 8 + 4096
+        pending = cur
     voff = torch.tensor([0] + [v.shape[0] for v in vs], dtype=torch.int64).cumsum(0)
     foff = torch.tensor([0] + [f.shape[0] for f in fs], dtype=torch.int64).cumsum(0)
     return torch.cat(vs), torch.cat(fs), voff, foff
