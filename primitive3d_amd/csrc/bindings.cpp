@@ -30,7 +30,11 @@ namespace {
 
 // output-size hints of the one-pass path, per (device, grid shape)
 using CapKey = std::tuple<int, int64_t, int64_t, int64_t>;
-std::map<CapKey, std::pair<int64_t, int64_t>> g_cap_hint;
+struct CapHint {
+    int64_t nv, nf;
+    int slack_q;  // headroom of every scratch region in quarters (5 = 1.25x); grows after a region overflow
+};
+std::map<CapKey, CapHint> g_cap_hint;
 std::mutex g_cap_mu;
 
 void check_rc(int rc, const char* what) {
@@ -76,6 +80,7 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     // One streaming pass into buffers of the given capacities (0,0 = count only).  The vertex scratch is cut into
     // 32 independently filled regions: `slack` is the headroom per region, and every region can hold 8192 rows
     // because a small output may come from very few wave-planes.  Returns true when everything fitted.
+    bool region_overflow = false;
     auto run_pass = [&](int64_t capv, int64_t capf, int64_t slack_num, int64_t slack_den) {
         Tensor scratch;
         int64_t scratch_rows = 0;
@@ -93,6 +98,7 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
                  "p3d_mc_extract_fused");
         int32_t overflow = 0;
         check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, &overflow, stream), "p3d_mc_read_counts");
+        region_overflow = overflow != 0 && nv <= capv;  // the total fitted, the split over the regions did not
         return nv <= capv && nf <= capf && !overflow;
     };
 
@@ -102,21 +108,24 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     // reference's two steps (count pass, then an exactly sized pass).
     const CapKey key{dev.index(), rx, ry, rz};
     int64_t capv = 0, capf = 0;
+    int slack_q = 5;
     if (!exact_mode) {
         std::lock_guard<std::mutex> g(g_cap_mu);
         auto it = g_cap_hint.find(key);
         if (it != g_cap_hint.end()) {
-            capv = it->second.first + it->second.first / 8 + 4096;
-            capf = it->second.second + it->second.second / 8 + 4096;
+            capv = it->second.nv + it->second.nv / 8 + 4096;
+            capf = it->second.nf + it->second.nf / 8 + 4096;
+            slack_q = it->second.slack_q;
         } else {
             capv = std::max<int64_t>(4096, rx * ry * rz / 16);
             capf = 2 * capv;
         }
     }
-    bool ok = run_pass(capv, capf, 5, 4);
+    bool ok = run_pass(capv, capf, slack_q, 4);
     {
+        // a field whose vertices are spread unevenly over the 32 regions gets more headroom per region next time
         std::lock_guard<std::mutex> g(g_cap_mu);
-        g_cap_hint[key] = {nv, nf};
+        g_cap_hint[key] = {nv, nf, region_overflow ? std::min(2 * slack_q, 32) : slack_q};
     }
     if (host_trace) {
         static double t_prev_out = 0.0;
@@ -127,7 +136,7 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     }
     if (!ok || exact_mode) {
         const int64_t ev = nv, ef = nf;  // exact sizes are known now
-        ok = run_pass(ev, ef, 2, 1);
+        ok = run_pass(ev, ef, std::max(8, 2 * slack_q), 4);
         if (!ok) {
             // pathological region imbalance: the gather emitter writes by vertex id and cannot overflow
             vertices = torch::empty({nv, 3}, vopt);

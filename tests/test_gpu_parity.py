@@ -196,3 +196,18 @@ def test_vertex_copy_split_between_the_two_face_launches(gpu, monkeypatch, early
     monkeypatch.setenv("P3D_COMPACT_EARLY", early)
     g, thresh, lower, upper = small_cases()["perlin_40x24x96_thr"]
     _assert_same_mesh(_hip_extract_fused(gpu, g, thresh, lower, upper), oracle_extract(g, thresh, lower, upper))
+
+
+def test_adapter_on_a_row_with_a_nearly_empty_last_z_tile(gpu, built):
+    """rz = 517: rows of 8 full chunks + 5 voxels, i.e. a second z tile of the streaming kernel that carries almost
+    nothing.  The vertices then spread unevenly over the scratch regions; the adapter must still return the exact
+    mesh (growing its per-region headroom), call after call."""
+    g = np.random.default_rng(21).standard_normal((24, 40, 517)).astype(np.float32)
+    nv, nf = oracle_count(g, 0.1)
+    t = torch.from_numpy(g).to(gpu)
+    for _ in range(3):
+        v, f = built.libPrim3D.marching_cubes(t, 0.1, [0.0, 0.0, 0.0], [24.0, 40.0, 517.0])
+        assert v.shape == (nv, 3) and f.shape == (nf, 3)
+    rv, rf, _ = oracle_extract(g, 0.1, [0.0, 0.0, 0.0], [24.0, 40.0, 517.0])
+    soup = lambda vv, ff: np.sort(vv[ff.astype(np.int64)].reshape(len(ff), 9).view([("", np.float32)] * 9), axis=0)
+    assert np.array_equal(soup(v.cpu().numpy(), f.cpu().numpy()), soup(rv, rf))
