@@ -12,15 +12,19 @@
  *   allocates torch tensors between the two phases -- see INTEGRATION.md.)
  *
  * Conventions
- *   - All pointers except `counts` outputs are DEVICE pointers owned by the caller; nothing is
- *     allocated, freed or retained by the library.  No torch types cross this boundary.
+ *   - All pointers except `counts` outputs are DEVICE pointers owned by the caller.  The library keeps two small
+ *     things of its own per device / stream: a ring of pre-cleared 4 KiB blocks for the streaming kernel's output
+ *     cursors and a 4 KiB pinned host mailbox through which the kernels report totals.  No torch types cross
+ *     this boundary.
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All calls enqueue work on
- *     it and return immediately, except p3d_mc_read_counts which synchronises the stream.
+ *     it and return immediately; p3d_mc_read_counts waits for the totals only (see there), not for the stream.
  *   - Grid layout is the reference's: contiguous [rx][ry][rz], z fastest (marching_cubes.cu:20).
  *   - Return value 0 on success, negative P3D_E* on failure; p3d_last_error() gives a thread-local
  *     message.
  *   - Vertex order and face order are unspecified (as in the reference, whose order is atomicAdd
- *     arrival order, marching_cubes.cu:104,199) but deterministic for a given build and input.
+ *     arrival order, marching_cubes.cu:104,199).  Here the face order is deterministic for a given build and
+ *     input; the one-pass call's vertex order is arrival order inside 32 regions (the counting call's is
+ *     deterministic).
  */
 #ifndef P3D_MC_H_
 #define P3D_MC_H_
