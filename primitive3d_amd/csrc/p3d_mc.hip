@@ -56,7 +56,7 @@ struct Dims {
 };
 
 struct Ws {  // byte offsets into the workspace
-    size_t hdr, bits, rec, cnt, bsum_v, bbase_v, chunk_sum, wave_off, total;
+    size_t hdr, bits, rec, cnt, bsum_v, bbase_v, chunk_sum, wave_off, tile_tris, total;
     int64_t nchunks;  // face chunks (tile column x face_chunk_planes planes)
     int xw;
     int64_t nb_v, nb_f, tpp;  // unit blocks, face blocks, face tiles per plane
@@ -117,6 +117,8 @@ Ws make_ws(const Dims& d) {
     o = align_up(o + (size_t)(w.nchunks + 1) * 4, 256);
     w.wave_off = o;    // first face of every (tile, wave), relative to its chunk
     o = align_up(o + (size_t)(w.nb_f + 1) * 4 * 4, 256);
+    w.tile_tris = o;   // triangles of every face tile (an empty tile's block returns at once)
+    o = align_up(o + (size_t)(w.nb_f + 1) * 4, 256);
     w.total = o;
     return w;
 }
@@ -432,6 +434,7 @@ struct FaceArgs {
     int xw;                // planes per chunk (face_chunk_planes)
     const u32* chunk_sum;  // [nchunks] triangles per chunk
     const u32* wave_off;   // [nb_f * 4] first face of (tile, wave) relative to its chunk
+    const u32* tile_tris;  // [nb_f] triangles of the tile
     const u64* cursors;    // xlate: the call's 32 vertex-region cursors
     u64* mb;               // result mailbox slot (or null) and the call's sequence number (compaction block 0 reports)
     u64 seq;
@@ -555,7 +558,8 @@ __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr
 template <int PB>
 __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restrict__ bits, Dims d, int64_t tpp, int xw,
                                                             u32* __restrict__ chunk_sum, u32* __restrict__ wave_off,
-                                                            CompactArgs cp, u64* __restrict__ hdr) {
+                                                            u32* __restrict__ tile_tris, CompactArgs cp,
+                                                            u64* __restrict__ hdr) {
     if ((int)blockIdx.x < cp.nblocks) {  // the launch's first blocks move vertices (uniform per block)
         compact_block(cp, hdr, nullptr, 0);
         return;
@@ -608,14 +612,19 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
                 const u64 S3 = (W3 >> 1) | ((u64)((nbs >> (2 * i + 1)) & 1u) << 63);
                 const u64 S1 = (W1 >> 1) | ((u64)((nbs >> (2 * i + 2)) & 1u) << 63);
                 const u64 S2 = (W2 >> 1) | ((u64)((nbs >> (2 * i + 3)) & 1u) << 63);
+                // cells with a sign change among their 8 corners; a wave none of whose 64 units has one skips the
+                // network (most waves of a sparse field: an object's SDF in a box)
+                const u64 act = (W0 | W1 | W2 | W3 | S0 | S1 | S2 | S3) & ~(W0 & W1 & W2 & W3 & S0 & S1 & S2 & S3) & cells;
+                if (__ballot(act != 0ull)) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    u32 o0, o1, o2;
-                    tri_count_bitsliced((u32)(W0 >> (32 * h)), (u32)(W1 >> (32 * h)), (u32)(W2 >> (32 * h)),
-                                        (u32)(W3 >> (32 * h)), (u32)(S0 >> (32 * h)), (u32)(S1 >> (32 * h)),
-                                        (u32)(S2 >> (32 * h)), (u32)(S3 >> (32 * h)), o0, o1, o2);
-                    const u32 m = (u32)(cells >> (32 * h));
-                    n += (u32)__popc(o0 & m) + 2u * (u32)__popc(o1 & m) + 4u * (u32)__popc(o2 & m);
+                    for (int h = 0; h < 2; ++h) {
+                        u32 o0, o1, o2;
+                        tri_count_bitsliced((u32)(W0 >> (32 * h)), (u32)(W1 >> (32 * h)), (u32)(W2 >> (32 * h)),
+                                            (u32)(W3 >> (32 * h)), (u32)(S0 >> (32 * h)), (u32)(S1 >> (32 * h)),
+                                            (u32)(S2 >> (32 * h)), (u32)(S3 >> (32 * h)), o0, o1, o2);
+                        const u32 m = (u32)(act >> (32 * h));
+                        n += (u32)__popc(o0 & m) + 2u * (u32)__popc(o1 & m) + 4u * (u32)__popc(o2 & m);
+                    }
                 }
             }
             n = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum(n), 63);
@@ -627,7 +636,9 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
                 u32 mine = running;
                 for (int w = 0; w < tid; ++w) mine += s_part[i][w];
                 wave_off[((xs + i) * tpp + tile) * 4 + tid] = mine;
-                running += s_part[i][0] + s_part[i][1] + s_part[i][2] + s_part[i][3];
+                const u32 all4 = s_part[i][0] + s_part[i][1] + s_part[i][2] + s_part[i][3];
+                if (tid == 0) tile_tris[(xs + i) * tpp + tile] = all4;
+                running += all4;
             }
         }
         __syncthreads();
@@ -746,6 +757,7 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     auto dense = [&](u32 v) -> u32 { return XLATE ? (v & 0x3ffffffu) + s_pref[(v >> 26) & (kRegions - 1)] : v; };
 
     const int64_t b = (int64_t)blockIdx.x - cp.nblocks;
+    if (a.tile_tris[b] == 0u) return;  // nothing to emit here (block-uniform; most tiles of a sparse field)
     const int64_t x = b / a.tpp;
     const int64_t tile = b - x * a.tpp;
     const int64_t p = tile * kBlock + tid;
@@ -1161,7 +1173,7 @@ int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3
         StageTimer tm(ST_FACES_COUNT, st);
         const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr};
         hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)w.nchunks), dim3(kBlock), 0, st, bits, d, w.tpp, w.xw, csum,
-                           woff, none, hdr);
+                           woff, (u32*)(ws + w.tile_tris), none, hdr);
     }
     {
         StageTimer tm(ST_SCAN_F, st);
@@ -1195,7 +1207,8 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
         StageTimer tm(ST_EMIT_FACES, st);
         const FaceArgs a{2, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
                          slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw,
-                         (const u32*)(ws + w.chunk_sum), (const u32*)(ws + w.wave_off), nullptr, nullptr, 0};
+                         (const u32*)(ws + w.chunk_sum), (const u32*)(ws + w.wave_off),
+                         (const u32*)(ws + w.tile_tris), nullptr, nullptr, 0};
         const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr};
         if (d.ncz <= 32)
             hipLaunchKernelGGL(k_faces<32>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, none, hdr, faces, capf);
@@ -1347,7 +1360,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         const CompactArgs cpe{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, early * kRegions, 0, nparts, 0,
                               csum, (int)w.nchunks, cursors};
         hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)(w.nchunks + cpe.nblocks)), dim3(kBlock), 0, st, bits,
-                           d, w.tpp, w.xw, csum, woff, cpe, hdr);
+                           d, w.tpp, w.xw, csum, woff, (u32*)(ws + w.tile_tris), cpe, hdr);
     }
     if (part == 4) {  // totals to the host now; the faces (and the rest of the vertex copy) follow in part 5
         StageTimer tm(ST_SCAN_F, st);
@@ -1357,7 +1370,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     }
     const FaceArgs a{1, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
                      slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw,
-                     csum, woff, cursors, mb, seq};
+                     csum, woff, (const u32*)(ws + w.tile_tris), cursors, mb, seq};
     const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, (nparts - early) * kRegions, early,
                          nparts, part == 5 ? 0 : 1, csum, (int)w.nchunks, cursors};
     StageTimer tm(ST_EMIT_FACES, st);
