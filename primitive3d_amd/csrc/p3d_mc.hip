@@ -603,28 +603,35 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
             }
         }
         if (!more) nbs = 0;
+        // A wave all of whose units are entirely outside (every word 0) or entirely inside (every word all ones)
+        // over the whole sub-batch has no cell with a sign change: it skips the networks (most waves of a sparse
+        // field -- an object's SDF in a box).  One OR / AND over the words already loaded; conservative on tail chunks.
+        u64 acc_or = 0, acc_and = ~0ull;
+        static_for<0, PB + 1>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            acc_or |= Wp[i] | Wq[i];
+            acc_and &= Wp[i] & Wq[i];
+        });
+        constexpr u32 kAllNext = (1u << (2 * (PB + 1))) - 1u;
+        const bool flat = !valid || (acc_or == 0ull && nbs == 0u) || (acc_and == ~0ull && (!more || nbs == kAllNext));
+        const bool wave_active = __ballot(!flat) != 0ull;
         static_for<0, PB>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             u32 n = 0;
-            if (xs + i < x_end) {  // block-uniform
+            if (xs + i < x_end && wave_active) {  // uniform
                 const u64 W0 = Wp[i], W1 = Wp[i + 1], W2 = Wq[i + 1], W3 = Wq[i];
                 const u64 S0 = (W0 >> 1) | ((u64)((nbs >> (2 * i)) & 1u) << 63);
                 const u64 S3 = (W3 >> 1) | ((u64)((nbs >> (2 * i + 1)) & 1u) << 63);
                 const u64 S1 = (W1 >> 1) | ((u64)((nbs >> (2 * i + 2)) & 1u) << 63);
                 const u64 S2 = (W2 >> 1) | ((u64)((nbs >> (2 * i + 3)) & 1u) << 63);
-                // cells with a sign change among their 8 corners; a wave none of whose 64 units has one skips the
-                // network (most waves of a sparse field: an object's SDF in a box)
-                const u64 act = (W0 | W1 | W2 | W3 | S0 | S1 | S2 | S3) & ~(W0 & W1 & W2 & W3 & S0 & S1 & S2 & S3) & cells;
-                if (__ballot(act != 0ull)) {
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        u32 o0, o1, o2;
-                        tri_count_bitsliced((u32)(W0 >> (32 * h)), (u32)(W1 >> (32 * h)), (u32)(W2 >> (32 * h)),
-                                            (u32)(W3 >> (32 * h)), (u32)(S0 >> (32 * h)), (u32)(S1 >> (32 * h)),
-                                            (u32)(S2 >> (32 * h)), (u32)(S3 >> (32 * h)), o0, o1, o2);
-                        const u32 m = (u32)(act >> (32 * h));
-                        n += (u32)__popc(o0 & m) + 2u * (u32)__popc(o1 & m) + 4u * (u32)__popc(o2 & m);
-                    }
+                for (int h = 0; h < 2; ++h) {
+                    u32 o0, o1, o2;
+                    tri_count_bitsliced((u32)(W0 >> (32 * h)), (u32)(W1 >> (32 * h)), (u32)(W2 >> (32 * h)),
+                                        (u32)(W3 >> (32 * h)), (u32)(S0 >> (32 * h)), (u32)(S1 >> (32 * h)),
+                                        (u32)(S2 >> (32 * h)), (u32)(S3 >> (32 * h)), o0, o1, o2);
+                    const u32 m = (u32)(cells >> (32 * h));
+                    n += (u32)__popc(o0 & m) + 2u * (u32)__popc(o1 & m) + 4u * (u32)__popc(o2 & m);
                 }
             }
             n = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum(n), 63);
