@@ -1,22 +1,9 @@
-"""The reference's examples/bunny_sdf.py on the MI355X build (input: the reference's bunny.npy, kept as
-tests/golden/bunny66.npy; known answer V=13282, F=26560)."""
-import os
-import sys
-from pathlib import Path
-
+"""Stanford-bunny SDF, the input of the reference's examples/bunny_sdf.py (its examples/data/bunny.npy, a 66^3 float
+grid, kept here as tests/golden/bunny66.npy), iso value 0.  The reference's kernels give V=13282, F=26560 on it."""
 import numpy as np
-import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))  # run from a source checkout
-import prim3d  # noqa: E402
-
-DENSITY_GRID = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "bunny66.npy"))
-print(f"DENSITY_GRID shape: ({DENSITY_GRID.shape[0]}, {DENSITY_GRID.shape[1]}, {DENSITY_GRID.shape[2]})")
+from _common import REPO, run_example
 
 if __name__ == "__main__":
-    density_grid_cu = torch.tensor(DENSITY_GRID).cuda()
-    with prim3d.Timer("cuda marching cubes: {:.6f}s"):
-        vertices_cu, faces_cu = prim3d.marching_cubes(density_grid_cu, 0, verbose=True)
-    with prim3d.Timer("prim3d save mesh: {:.6f}s\n"):
-        prim3d.save_mesh(vertices_cu, faces_cu, filename="bunny.ply")
-    assert vertices_cu.shape[0] == 13282 and faces_cu.shape[0] == 26560
+    sdf = np.load(REPO / "tests" / "golden" / "bunny66.npy")
+    run_example("bunny", sdf, 0, expected=(13282, 26560))

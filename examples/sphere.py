@@ -1,30 +1,12 @@
-"""The reference's acceptance script (examples/sphere.py) on the MI355X build: 200^3 int64 sphere,
-GPU extraction through `prim3d.marching_cubes`, PLY export, counts asserted against the reference's
-known answer (V=11766, F=23528; the reference compares with PyMCubes, which is used here only if
-installed)."""
-import sys
-from pathlib import Path
-
+"""Sphere SDF, the input of the reference's examples/sphere.py: a 200^3 integer grid holding
+(x-50)^2 + (y-50)^2 + (z-50)^2 - 25^2, iso value 0.  The reference's kernels give V=11766, F=23528 on it."""
 import numpy as np
-import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))  # run from a source checkout
-import prim3d  # noqa: E402
+from _common import run_example
 
-X, Y, Z = np.mgrid[:200, :200, :200]
-DENSITY_GRID = (X - 50) ** 2 + (Y - 50) ** 2 + (Z - 50) ** 2 - 25 ** 2
+N, CENTRE, RADIUS = 200, 50, 25
 
 if __name__ == "__main__":
-    density_grid_cu = torch.tensor(DENSITY_GRID).cuda()
-    with prim3d.Timer("cuda marching cubes: {:.6f}s"):
-        vertices_cu, faces_cu = prim3d.marching_cubes(density_grid_cu, 0, verbose=True)
-    with prim3d.Timer("prim3d save mesh: {:.6f}s\n"):
-        prim3d.save_mesh(vertices_cu, faces_cu, filename="sphere.ply")
-    assert vertices_cu.shape[0] == 11766 and faces_cu.shape[0] == 23528
-    try:
-        import mcubes
-        with prim3d.Timer("cpu marching cubes: {:.6f}s"):
-            vertices_c, faces_c = mcubes.marching_cubes(DENSITY_GRID, 0)
-        assert vertices_cu.shape[0] == vertices_c.shape[0] and faces_cu.shape[0] == faces_c.shape[0]
-    except ImportError:
-        print("mcubes not installed: compared with the recorded reference counts only")
+    axis = np.arange(N, dtype=np.int64) - CENTRE
+    sdf = (axis[:, None, None] ** 2 + axis[None, :, None] ** 2 + axis[None, None, :] ** 2) - RADIUS ** 2
+    run_example("sphere", sdf, 0, expected=(11766, 23528))

@@ -29,6 +29,38 @@ def scale_to_bound(scale: Union[float, Sequence]) -> Tuple[List[float]]:
     return [v for v in scale[0]], [v for v in scale[1]]
 
 
+def _bounding_box(shape, scale):
+    """(lower, upper) of the box the grid spans: [0, shape] when no scale is given (upper keeps Python ints then, as
+    in the reference, :59-62), else whatever scale_to_bound makes of `scale`."""
+    if scale is not None:
+        return scale_to_bound(scale)
+    return [0.0, 0.0, 0.0], [shape[0], shape[1], shape[2]]
+
+
+def _via_pymcubes(density_grid, thresh, lower, upper):
+    """The reference's CPU branch (:66-81): third-party PyMCubes plus its rescaling, including the division by the
+    voxel size (:78).  PyMCubes is not a dependency here: without it the reference's own ImportError is raised."""
+    try:
+        import mcubes
+    except:  # noqa: E722  (any failure of the import counts, as in the reference, :69)
+        raise ImportError("the cpu mode cumcubes is the wrapper of `mcubes`, please install the mcubes")
+    host_grid = density_grid.detach().cpu().numpy()
+    verts, tris = mcubes.marching_cubes(host_grid, thresh)
+    voxel = (np.array(upper) - np.array(lower)) / np.array(host_grid.shape)
+    return torch.tensor(verts / voxel + np.array(lower)), torch.tensor(tris.astype(np.int64))
+
+
+def _on_device_as_float32(density_grid):
+    """ndarray -> tensor -> device -> float32 (:84-87; a non-contiguous tensor stays non-contiguous and is rejected
+    by the native module, like in the reference); grids thinner than 2 samples along any axis: bare ValueError."""
+    if isinstance(density_grid, np.ndarray):
+        density_grid = torch.tensor(density_grid)
+    density_grid = density_grid.cuda().to(torch.float32)
+    if min(density_grid.shape[0], density_grid.shape[1], density_grid.shape[2]) < 2:
+        raise ValueError()
+    return density_grid
+
+
 def marching_cubes(
     density_grid: Union[torch.Tensor, np.ndarray],
     thresh: float,
@@ -36,40 +68,14 @@ def marching_cubes(
     verbose: bool = False,
     cpu: bool = False,
 ) -> Tuple[torch.Tensor]:
-    """reference: prim3d/utility/marching_cubes.py:34-98.
-
-    GPU branch: ndarray -> tensor, .cuda(), .to(float32) (:84-87); any dim < 2 -> ValueError() (:89-90);
-    returns (vertices f32 [V,3], faces i32 [F,3]) on the device.
-    cpu=True (or no GPU): the reference's wrapper of third-party PyMCubes (:66-81), kept verbatim in
-    behaviour -- it needs `mcubes` installed and raises the reference's ImportError otherwise.
-    """
-    if scale is None:
-        lower = [0.0, 0.0, 0.0]
-        upper = [density_grid.shape[0], density_grid.shape[1], density_grid.shape[2]]
-    else:
-        lower, upper = scale_to_bound(scale)
-
+    """Same call as the reference's wrapper (prim3d/utility/marching_cubes.py:34-98): returns
+    (vertices f32 [V,3], faces i32 [F,3]) on the device; `scale` as in scale_to_bound; `verbose` prints the two
+    counts; `cpu=True` (or no GPU) takes the PyMCubes branch, which yields f64 vertices / i64 faces on the host."""
+    lower, upper = _bounding_box(density_grid.shape, scale)
     if cpu or not torch.cuda.is_available():
-        try:
-            import mcubes
-        except:  # noqa: E722  (the reference catches everything, :69)
-            raise ImportError("the cpu mode cumcubes is the wrapper of `mcubes`, please install the mcubes")
-        density_grid = density_grid.detach().cpu().numpy()
-        vertices, faces = mcubes.marching_cubes(density_grid, thresh)
-        offset = np.array(lower)
-        vscale = (np.array(upper) - np.array(lower)) / np.array(density_grid.shape)
-        vertices = vertices / vscale + offset  # the reference divides here (:78)
-        vertices = torch.tensor(vertices)
-        faces = torch.tensor(faces.astype(np.int64))
+        vertices, faces = _via_pymcubes(density_grid, thresh, lower, upper)
     else:
-        if isinstance(density_grid, np.ndarray):
-            density_grid = torch.tensor(density_grid)
-        density_grid = density_grid.cuda()
-        density_grid = density_grid.to(torch.float32)
-        if density_grid.shape[0] < 2 or density_grid.shape[1] < 2 or density_grid.shape[2] < 2:
-            raise ValueError()
-        vertices, faces = _C.marching_cubes(density_grid, thresh, lower, upper)
-
+        vertices, faces = _C.marching_cubes(_on_device_as_float32(density_grid), thresh, lower, upper)
     if verbose:
         print(f"#vertices={vertices.shape[0]}")
         print(f"#triangles={faces.shape[0]}")
@@ -83,25 +89,18 @@ def save_mesh(
     filename: Union[str, Path] = "temp.ply",
     verbose: bool = False,
 ) -> None:
-    """reference: prim3d/utility/marching_cubes.py:100-141."""
-    if isinstance(filename, Path):
-        filename = str(filename)
-    if isinstance(vertices, np.ndarray):
-        vertices = torch.tensor(vertices)
-    if isinstance(faces, np.ndarray):
-        faces = torch.tensor(faces)
-    faces = faces.int()
-    if colors is None:
-        colors = torch.ones_like(vertices) * 127
-    elif isinstance(colors, np.ndarray):
-        colors = torch.tensor(colors)
-    colors = colors.to(torch.uint8)
-    if filename.endswith(".ply"):
-        _C.save_mesh_as_ply(filename, vertices, faces, colors)
-    else:
+    """Same call as the reference's save_mesh (:100-141): int32 faces, uint8 colours (mid grey when none are given),
+    only the .ply format exists."""
+    as_tensor = lambda a: torch.tensor(a) if isinstance(a, np.ndarray) else a  # noqa: E731
+    name = str(filename) if isinstance(filename, Path) else filename
+    vertices = as_tensor(vertices)
+    faces = as_tensor(faces).int()
+    colors = (torch.ones_like(vertices) * 127 if colors is None else as_tensor(colors)).to(torch.uint8)
+    if not name.endswith(".ply"):
         raise NotImplementedError()
+    _C.save_mesh_as_ply(name, vertices, faces, colors)
     if verbose:
-        print(f"save as {filename} successfully!")
+        print(f"save as {name} successfully!")
 
 
 def marching_cubes_batched(density_grids, thresh: float, scale=None):
