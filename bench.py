@@ -30,6 +30,77 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
 SHAPES = {1: (512, 512, 512), 2: (1024, 512, 512), 4: (1024, 1024, 512), 8: (1024, 1024, 1024)}
 
 
+def soup_hashes(v, f):
+    """Order-free fingerprint of a mesh on the device: one 64-bit hash per triangle of the BIT PATTERNS of its nine
+    coordinates in corner order (winding kept), sorted; plus the sorted vertex rows themselves."""
+    import torch
+    bits = v.contiguous().view(torch.int32)[f.long()].reshape(-1, 9).long() & 0xFFFFFFFF
+    h = torch.zeros(bits.shape[0], dtype=torch.int64, device=v.device)
+    for k in range(9):
+        h = (h ^ bits[:, k]) * -7046029254386353131 + (k + 1)
+        h = h ^ (h >> 29)
+    vb = v.contiguous().view(torch.int32).long() & 0xFFFFFFFF
+    vkey = torch.sort((vb[:, 0] * 0x9E3779B1 + vb[:, 1]) * 0x85EBCA6B + vb[:, 2]).values
+    return torch.sort(h).values, vkey
+
+
+def cpu_baseline(grid, thresh, lower, upper, out_v, out_f):
+    """The CPU leg (rank 0, N=1): the oracle restatement of the reference kernels (`kind: "port"`) timed on the host
+    cores next to the GPU number -- one thread and all cores (OpenMP over axis-0 planes) -- and, when PyMCubes is
+    importable, the reference's own CPU path `mcubes.marching_cubes` (marching_cubes.py:74; `kind: "reference"`).
+    The GPU mesh of the last timed call is compared with the oracle's as a WHOLE (sorted triangle soups, positions
+    bit for bit), not only by its counts.  A baseline, not a target."""
+    import numpy as np
+    from oracle import oracle_count, oracle_extract
+    rx, ry, rz = grid.shape
+    nvox = rx * ry * rz
+    g = grid.cpu().numpy()
+    counts = oracle_count(g, thresh)
+    # bounded sample: whole extractions of the same grid, ~8 s of single-thread work, then ~6 s on all cores
+    reps1, c0 = 0, time.perf_counter()
+    while True:
+        ov, of, _ = oracle_extract(g, thresh, lower, upper, counts=counts, want_keys=False)
+        reps1 += 1
+        c1 = time.perf_counter()
+        if c1 - c0 >= 8.0 or reps1 >= 8:
+            break
+    t1 = (c1 - c0) / reps1
+    repsn, c0 = 0, time.perf_counter()
+    while True:
+        mv, mf, _ = oracle_extract(g, thresh, lower, upper, threads=0, counts=counts, want_keys=False)
+        repsn += 1
+        c1 = time.perf_counter()
+        if c1 - c0 >= 6.0 or repsn >= 32:
+            break
+    tn = (c1 - c0) / repsn
+    nthreads = int(getattr(oracle_extract, "last_threads", 1))
+    import torch
+    gv, gf = out_v, out_f
+    assert tuple(ov.shape) == tuple(gv.shape) and tuple(of.shape) == tuple(gf.shape), \
+        ("GPU/CPU count mismatch", ov.shape, of.shape, gv.shape, gf.shape)
+    assert np.array_equal(mv, ov) and np.array_equal(mf, of), "OpenMP oracle differs from the serial oracle"
+    hg, kg = soup_hashes(gv, gf)
+    ho, ko = soup_hashes(torch.from_numpy(ov).to(gv.device), torch.from_numpy(of).to(gv.device))
+    assert torch.equal(kg, ko), "GPU vertex positions differ from the CPU oracle's"
+    assert torch.equal(hg, ho), "GPU mesh differs from the CPU oracle's (triangle soup)"
+    res = {"value": round(nvox / tn / 1e6, 2), "unit": "Mvoxels/s", "cores": nthreads, "kind": "port",
+           "sample": f"{repsn} full extractions of the same {rx}x{ry}x{rz} grid by oracle/mc_oracle.c with OpenMP on "
+                     f"{nthreads} threads ({tn:.2f} s each); single thread: {reps1} extractions, {t1:.2f} s each = "
+                     f"{nvox / t1 / 1e6:.1f} Mvoxels/s; host has {os.cpu_count()} cores; whole GPU mesh "
+                     f"(V={gv.shape[0]}, F={gf.shape[0]}) compared bit for bit with the oracle's as a sorted triangle soup",
+           "single_thread_value": round(nvox / t1 / 1e6, 2)}
+    try:  # the reference's own CPU branch is third-party PyMCubes (single-threaded): timed as examples/sphere.py:22-23
+        import mcubes
+        c0 = time.perf_counter()
+        pv, pf = mcubes.marching_cubes(g, thresh)
+        tm = time.perf_counter() - c0
+        res["pymcubes"] = {"value": round(nvox / tm / 1e6, 2), "unit": "Mvoxels/s", "cores": 1, "kind": "reference",
+                           "vertices": int(pv.shape[0]), "faces": int(pf.shape[0])}
+    except Exception as e:  # not installed in this image (SURVEY.md 8c)
+        res["pymcubes"] = f"unavailable ({type(e).__name__})"
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -49,6 +120,7 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: they must agree")
     # dev-only overrides to dry-run the N>1 code path on a 1-GPU box: all ranks on cuda:0, gloo transport
     share = os.environ.get("P3D_BENCH_SHARE_DEVICE") == "1"
     backend = os.environ.get("P3D_BENCH_BACKEND", "nccl")
@@ -99,7 +171,14 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    # cold call: the first call on this shape has no size hint (density guess, maybe a second streaming pass) and pays
+    # the library's one-time setup; reported once, never part of `value`
+    torch.cuda.synchronize()
+    c0 = time.perf_counter()
+    out = step()
+    torch.cuda.synchronize()
+    cold_ms = (time.perf_counter() - c0) * 1e3
+    for _ in range(max(0, args.warmup - 1)):
         out = step()
     torch.cuda.synchronize()
 
@@ -119,6 +198,18 @@ def main():
     barrier()
     t1 = time.perf_counter()
     capi.profile_enable(0)
+
+    # SURVEY.md 8d also asks for the per-call median: >= 10 calls, each bracketed by events on the call's stream
+    # (after the timed region: event packets between the calls perturb the back-to-back stream slightly)
+    call_ms = []
+    if world == 1:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(15)]
+        for e0, e1 in evs:
+            e0.record()
+            out = step()
+            e1.record()
+        torch.cuda.synchronize()
+        call_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
 
     elapsed = t1 - t0
     if world > 1:
@@ -153,11 +244,16 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_kernel_ms": round(avg_ms, 4), "alg_bytes_per_launch": alg_bytes,
                     "whole_call_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if call_ms:
+            roofline["call_median_ms_hipevents"] = round(call_ms[len(call_ms) // 2], 4)
+        roofline["cold_first_call_ms"] = round(cold_ms, 3)
         if args.stages:
             print("stage ms/step:", {k: round(v / args.steps, 4) for k, v in stage_acc.items()}, file=sys.stderr)
 
         line = {
-            "metric": "Mvoxels/s on 512^3 fp32 SDF (whole marching_cubes call, device-resident grid)",
+            "metric": f"Mvoxels/s on {rx}x{ry}x{rz} fp32 SDF (whole marching_cubes call, device-resident grid)"
+                      if (rx, ry, rz) != (512, 512, 512) else
+                      "Mvoxels/s on 512^3 fp32 SDF (whole marching_cubes call, device-resident grid)",
             "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -167,21 +263,7 @@ def main():
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import oracle_extract
-            g = grid.cpu().numpy()
-            reps, c0 = 0, time.perf_counter()
-            while True:  # bounded sample: whole extractions of the same grid until ~10 s of CPU work
-                ov, of, _ = oracle_extract(g, thresh, lower, upper)
-                reps += 1
-                c1 = time.perf_counter()
-                if c1 - c0 >= 10.0 or reps >= 8:
-                    break
-            assert ov.shape[0] == nv and of.shape[0] == nf, ("GPU/CPU count mismatch", ov.shape, of.shape, nv, nf)
-            line["cpu_baseline"] = {"value": round(nvox_total * reps / (c1 - c0) / 1e6, 2), "unit": "Mvoxels/s",
-                                    "cores": 1, "kind": "port",
-                                    "sample": f"{reps} full extractions of the same {rx}x{ry}x{rz} grid by "
-                                              f"oracle/mc_oracle.c ({c1 - c0:.1f} s total, single thread); "
-                                              f"host has {os.cpu_count()} cores"}
+            line["cpu_baseline"] = cpu_baseline(grid, thresh, lower, upper, out_v, out_f)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

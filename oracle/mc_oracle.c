@@ -95,6 +95,9 @@ int p3d_oracle_count(const float* grid, int64_t rx, int64_t ry, int64_t rz, floa
     return 0;
 }
 
+static void p3d_oracle_epilogue(int64_t rx, int64_t ry, int64_t rz, const float* lower, const float* upper,
+                                float* verts, int64_t cursor);
+
 /*
  * Full extraction.  verts: float[V*3], vkeys: int64[V] (edge key, may be NULL), faces: int32[F*3].
  * V and F must come from p3d_oracle_count.  lower/upper as the pybind boundary hands them over
@@ -187,8 +190,14 @@ int p3d_oracle_extract(const float* grid, int64_t rx, int64_t ry, int64_t rz, fl
                 }
             }
     free(vgrid);
+    p3d_oracle_epilogue(rx, ry, rz, lower, upper, verts, cursor);
+    return 0;
+}
 
-    /* epilogue, marching_cubes.cu:290-298.  NOTE the reference quirk at :295: the y scale uses
+/* epilogue, marching_cubes.cu:290-298. (shared by the serial and the OpenMP driver) */
+static void p3d_oracle_epilogue(int64_t rx, int64_t ry, int64_t rz, const float* lower, const float* upper,
+                                float* verts, int64_t cursor) {
+    /* marching_cubes.cu:290-298.  NOTE the reference quirk at :295: the y scale uses
      * upper[2] - lower[1].  vertices = vertices * scale + offset, two separately rounded ops. */
     const float scale[3] = {(upper[0] - lower[0]) / (float)rx, (upper[2] - lower[1]) / (float)ry,
                             (upper[2] - lower[2]) / (float)rz};
@@ -197,5 +206,116 @@ int p3d_oracle_extract(const float* grid, int64_t rx, int64_t ry, int64_t rz, fl
             volatile float m = verts[i * 3 + a] * scale[a];
             verts[i * 3 + a] = m + lower[a];
         }
-    return 0;
+}
+
+/*
+ * The same extraction on `nthreads` host cores (OpenMP over axis-0 planes; SURVEY.md section 8d "all host cores"
+ * CPU baseline).  Every plane's vertex and face-index counts are taken first (the reference's counting kernel,
+ * marching_cubes.cu:4-68, per plane), an exclusive prefix over the planes gives each plane its first vertex id and
+ * first face slot, and the planes are then filled independently with exactly the loops of p3d_oracle_extract above:
+ * the output (values AND order) is identical to the serial oracle's, which tests/test_oracle_cpu.py asserts.
+ * Returns the number of threads actually used (>0), negative on error.
+ */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int p3d_oracle_extract_mt(const float* grid, int64_t rx, int64_t ry, int64_t rz, float thresh, const float* lower,
+                          const float* upper, float* verts, int64_t* vkeys, int32_t* faces, int nthreads) {
+    if (rx < 1 || ry < 1 || rz < 1) return -1;
+    const int64_t sy = rz, sx = ry * rz;
+    const int64_t nvox = rx * ry * rz;
+    int32_t* vgrid = (int32_t*)calloc((size_t)nvox * 3, sizeof(int32_t));
+    int64_t* vfirst = (int64_t*)calloc((size_t)rx + 1, sizeof(int64_t));
+    int64_t* ffirst = (int64_t*)calloc((size_t)rx + 1, sizeof(int64_t));
+    if (!vgrid || !vfirst || !ffirst) {
+        free(vgrid);
+        free(vfirst);
+        free(ffirst);
+        return -2;
+    }
+    int used = 1;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel
+    {
+#pragma omp single
+        used = omp_get_num_threads();
+    }
+#else
+    (void)nthreads;
+#endif
+    /* per-plane counts (count_vertices_faces_kernel restricted to one x) */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t x = 0; x < rx; ++x) {
+        int64_t nv = 0, nf = 0;
+        for (int64_t y = 0; y < ry; ++y)
+            for (int64_t z = 0; z < rz; ++z) {
+                const float* p = grid + x * sx + y * sy + z;
+                const int inside = p[0] > thresh;
+                if (x < rx - 1 && inside != (p[sx] > thresh)) ++nv;
+                if (y < ry - 1 && inside != (p[sy] > thresh)) ++nv;
+                if (z < rz - 1 && inside != (p[1] > thresh)) ++nv;
+                if (x < rx - 1 && y < ry - 1 && z < rz - 1)
+                    nf += tri_index_count(cell_mask(grid, sy, sx, x, y, z, thresh));
+            }
+        vfirst[x + 1] = nv;
+        ffirst[x + 1] = nf;
+    }
+    for (int64_t x = 0; x < rx; ++x) {
+        vfirst[x + 1] += vfirst[x];
+        ffirst[x + 1] += ffirst[x];
+    }
+    /* gen_vertices_kernel per plane, marching_cubes.cu:70-138 */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t x = 0; x < rx; ++x) {
+        int64_t cursor = vfirst[x];
+        for (int64_t y = 0; y < ry; ++y)
+            for (int64_t z = 0; z < rz; ++z) {
+                const int64_t lin = x * sx + y * sy + z;
+                const float d0 = grid[lin];
+                const int inside = d0 > thresh;
+                int32_t* cur = vgrid + lin * 3;
+                for (int a = 0; a < 3; ++a) {
+                    const int64_t lim = a == 0 ? rx : (a == 1 ? ry : rz), pos = a == 0 ? x : (a == 1 ? y : z);
+                    const int64_t step = a == 0 ? sx : (a == 1 ? sy : 1);
+                    if (pos >= lim - 1) continue;
+                    const float d1 = grid[lin + step];
+                    if (inside == (d1 > thresh)) continue;
+                    const float dt = (thresh - d0) / (d1 - d0); /* :105,:118,:131 */
+                    cur[a] = (int32_t)(cursor + 1);
+                    verts[cursor * 3 + 0] = (float)x + (a == 0 ? dt : 0.0f);
+                    verts[cursor * 3 + 1] = (float)y + (a == 1 ? dt : 0.0f);
+                    verts[cursor * 3 + 2] = (float)z + (a == 2 ? dt : 0.0f);
+                    if (vkeys) vkeys[cursor] = lin * 3 + a;
+                    ++cursor;
+                }
+            }
+    }
+    /* gen_faces_kernel per cell layer, marching_cubes.cu:140-209 */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t x = 0; x < rx - 1; ++x) {
+        int64_t fcur = ffirst[x];
+        for (int64_t y = 0; y + 1 < ry; ++y)
+            for (int64_t z = 0; z + 1 < rz; ++z) {
+                const int mask = cell_mask(grid, sy, sx, x, y, z, thresh);
+                if (tri_entry(mask, 0) < 0) continue;
+                const int64_t lin = x * sx + y * sy + z;
+#define VG(dx, dy, dz, a) vgrid[(lin + (dx)*sx + (dy)*sy + (dz)) * 3 + (a)]
+                const int32_t e[12] = {VG(0, 0, 0, 0), VG(1, 0, 0, 1), VG(0, 1, 0, 0), VG(0, 0, 0, 1),
+                                       VG(0, 0, 1, 0), VG(1, 0, 1, 1), VG(0, 1, 1, 0), VG(0, 0, 1, 1),
+                                       VG(0, 0, 0, 2), VG(1, 0, 0, 2), VG(1, 1, 0, 2), VG(0, 1, 0, 2)};
+#undef VG
+                for (int i = 0; i < 15; ++i) {
+                    const int j = tri_entry(mask, i);
+                    if (j < 0) break;
+                    faces[fcur++] = e[j] - 1;
+                }
+            }
+    }
+    const int64_t nv_total = vfirst[rx];
+    free(vgrid);
+    free(vfirst);
+    free(ffirst);
+    p3d_oracle_epilogue(rx, ry, rz, lower, upper, verts, nv_total);
+    return used;
 }

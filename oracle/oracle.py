@@ -32,6 +32,8 @@ def _lib():
         lib.p3d_oracle_count.restype = ctypes.c_int
         lib.p3d_oracle_extract.argtypes = [p, i64, i64, i64, f32, p, p, p, p, p]
         lib.p3d_oracle_extract.restype = ctypes.c_int
+        lib.p3d_oracle_extract_mt.argtypes = [p, i64, i64, i64, f32, p, p, p, p, p, ctypes.c_int]
+        lib.p3d_oracle_extract_mt.restype = ctypes.c_int
         lib.p3d_oracle_tri_table.argtypes = [p]
         lib.p3d_oracle_tri_table.restype = None
         _LIB = lib
@@ -61,9 +63,10 @@ def oracle_count(grid, thresh: float):
     return v.value, f3.value // 3
 
 
-def oracle_extract(grid, thresh: float, lower=None, upper=None):
+def oracle_extract(grid, thresh: float, lower=None, upper=None, threads: int = 1, counts=None, want_keys=True):
     """Returns (vertices f32 [V,3], faces i32 [F,3], vkeys i64 [V]); deterministic order
-    (vertices by (voxel, axis), faces by (cell, table slot))."""
+    (vertices by (voxel, axis), faces by (cell, table slot)).  threads > 1 (0 = all host cores) runs the OpenMP
+    driver p3d_oracle_extract_mt, whose output is identical; `counts` = (V, F) skips the counting pass."""
     g = _as_f32_grid(grid)
     if lower is None:
         lower = [0.0, 0.0, 0.0]
@@ -71,14 +74,22 @@ def oracle_extract(grid, thresh: float, lower=None, upper=None):
         upper = [float(s) for s in g.shape]
     lo = np.asarray(lower, dtype=np.float32)
     up = np.asarray(upper, dtype=np.float32)
-    nv, nf = oracle_count(g, thresh)
+    nv, nf = counts if counts is not None else oracle_count(g, thresh)
     verts = np.zeros((nv, 3), dtype=np.float32)
-    keys = np.zeros((nv,), dtype=np.int64)
+    keys = np.zeros((nv,), dtype=np.int64) if want_keys else None
     faces = np.zeros((nf, 3), dtype=np.int32)
-    rc = _lib().p3d_oracle_extract(g.ctypes.data, g.shape[0], g.shape[1], g.shape[2],
-                                   np.float32(thresh), lo.ctypes.data, up.ctypes.data,
-                                   verts.ctypes.data, keys.ctypes.data, faces.ctypes.data)
-    assert rc == 0
+    kp = keys.ctypes.data if want_keys else None
+    if threads == 1:
+        rc = _lib().p3d_oracle_extract(g.ctypes.data, g.shape[0], g.shape[1], g.shape[2],
+                                       np.float32(thresh), lo.ctypes.data, up.ctypes.data,
+                                       verts.ctypes.data, kp, faces.ctypes.data)
+        assert rc == 0
+    else:
+        rc = _lib().p3d_oracle_extract_mt(g.ctypes.data, g.shape[0], g.shape[1], g.shape[2],
+                                          np.float32(thresh), lo.ctypes.data, up.ctypes.data,
+                                          verts.ctypes.data, kp, faces.ctypes.data, int(threads))
+        assert rc > 0
+        oracle_extract.last_threads = rc
     return verts, faces, keys
 
 

@@ -128,3 +128,17 @@ def test_bitsliced_count_network_is_current(tmp_path, monkeypatch):
     monkeypatch.setattr(gen, "OUT", out)
     assert gen.main() == 0
     assert out.read_text() == (root / "primitive3d_amd" / "csrc" / "tri_count_bitsliced.inc").read_text()
+
+
+@pytest.mark.parametrize("threads", [0, 3])
+def test_openmp_oracle_is_identical_to_the_serial_one(threads):
+    """p3d_oracle_extract_mt (bench.py's all-host-cores CPU baseline) must give the serial oracle's output, values
+    and order, on every seeded case and on the reference's bunny input."""
+    from pathlib import Path
+    cases = dict(small_cases())
+    cases["bunny66"] = (np.load(Path(__file__).parent / "golden" / "bunny66.npy"), 0.0, None, None)
+    for name, (g, thresh, lower, upper) in cases.items():
+        a = oracle_extract(g, thresh, lower, upper)
+        b = oracle_extract(g, thresh, lower, upper, threads=threads)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y, equal_nan=True), name
