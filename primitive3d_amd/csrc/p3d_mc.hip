@@ -948,6 +948,8 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     }
 }
 
+#include "faces_walk.inc"
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -1143,6 +1145,27 @@ bool mailbox_wait(const void* ws, u64* nv, u64* nf, u64* flags) {
     return true;
 }
 
+// the face launch: `nface_tiles` > 0 emits triangles (else the launch consists of the compaction blocks only)
+void launch_faces(const Dims& d, const Ws& w, const u64* bits, const uint2* rec, const FaceArgs& a, const CompactArgs& cp,
+                  u64* hdr, int32_t* faces, int64_t capf, bool faces_here, hipStream_t st) {
+    if (env_int("P3D_FACES_OLD", 0)) {
+        const dim3 fgrid((u32)((faces_here ? w.nb_f : 0) + cp.nblocks));
+        if (d.ncz <= 32)
+            hipLaunchKernelGGL(k_faces<32>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
+        else
+            hipLaunchKernelGGL(k_faces<256>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
+        return;
+    }
+    const FaceLayout L = make_face_layout(d);
+    int xs = env_int("P3D_FACE_XS", 2);
+    if (xs < 1) xs = 1;
+    while (xs > 1 && (w.xw % xs) != 0) --xs;   // a segment must lie inside one count chunk
+    const int64_t nseg = d.rx > 1 ? (d.rx - 1 + xs - 1) / xs : 0;
+    const dim3 fgrid((u32)((faces_here ? nseg * w.tpp : 0) + cp.nblocks));
+    if (fgrid.x == 0) return;
+    hipLaunchKernelGGL(k_faces_walk, fgrid, dim3(kBlock), (size_t)L.total, st, bits, rec, d, a, cp, L, xs, hdr, faces, capf);
+}
+
 template <typename T>
 int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3d_mc_slab* slab, char* ws,
                hipStream_t st) {
@@ -1217,10 +1240,7 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
                          (const u32*)(ws + w.chunk_sum), (const u32*)(ws + w.wave_off),
                          (const u32*)(ws + w.tile_tris), nullptr, nullptr, 0};
         const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr};
-        if (d.ncz <= 32)
-            hipLaunchKernelGGL(k_faces<32>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, none, hdr, faces, capf);
-        else
-            hipLaunchKernelGGL(k_faces<256>, dim3((u32)w.nb_f), dim3(kBlock), 0, st, bits, rec, d, a, none, hdr, faces, capf);
+        launch_faces(d, w, bits, rec, a, none, hdr, faces, capf, true, st);
     }
     HIP_TRY(hipGetLastError());
     return P3D_OK;
@@ -1381,11 +1401,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, (nparts - early) * kRegions, early,
                          nparts, part == 5 ? 0 : 1, csum, (int)w.nchunks, cursors};
     StageTimer tm(ST_EMIT_FACES, st);
-    const dim3 fgrid((u32)((faces_here ? w.nb_f : 0) + cp.nblocks));
-    if (d.ncz <= 32)
-        hipLaunchKernelGGL(k_faces<32>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
-    else
-        hipLaunchKernelGGL(k_faces<256>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
+    launch_faces(d, w, bits, rec, a, cp, hdr, faces, capf, faces_here, st);
     HIP_TRY(hipGetLastError());
     return P3D_OK;
 }
