@@ -764,7 +764,7 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     auto dense = [&](u32 v) -> u32 { return XLATE ? (v & 0x3ffffffu) + s_pref[(v >> 26) & (kRegions - 1)] : v; };
 
     const int64_t b = (int64_t)blockIdx.x - cp.nblocks;
-    if (a.tile_tris[b] == 0u) return;  // nothing to emit here (block-uniform; most tiles of a sparse field)
+    const u32 my_tris = a.tile_tris[b];   // (the loads below are issued before this value is looked at)
     const int64_t x = b / a.tpp;
     const int64_t tile = b - x * a.tpp;
     const int64_t p = tile * kBlock + tid;
@@ -776,26 +776,49 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     // phase A: the units [tile start, +256) of planes x and x+1, the same ranges one row up (y+1: "+ncz" units, or a
     // second range of 256 when a row is longer than NHALO chunks), and one unit more (the z+1 neighbour of the last).
     // A cell's four columns W00,W10,W11,W01 are then plane 0/1 at index t and t + hoff.
+    // All global loads of the prologue are issued back to back (one memory round trip): the tile's triangle count,
+    // the staged words and records, and this thread's share of the chunk totals.
     const bool one_range = d.ncz <= NHALO;
     const int hoff = one_range ? d.ncz : kBlock + 1;   // index distance of the y+1 column
     const int nstage = one_range ? kBlock + d.ncz + 1 : 2 * (kBlock + 1);
     const int64_t p0 = tile * kBlock;
-    for (int i = tid; i < nstage; i += kBlock) {
-        const int64_t pi = (one_range || i <= kBlock) ? p0 + i : p0 + d.ncz + (i - kBlock - 1);
-        const bool ex = pi < d.P;
-        const int64_t ui = x * d.P + pi;
-        s_w[0][i] = ex ? bits[ui] : 0ull;
-        s_w[1][i] = ex ? bits[ui + d.P] : 0ull;
-        if (ex) {
-            s_r[0][i] = rec[ui];  // only entries of units that own vertices are meaningful
-            s_r[1][i] = rec[ui + d.P];
+    constexpr int NST = (NS + kBlock - 1) / kBlock;   // staged entries per thread
+    u64 st_w0[NST], st_w1[NST];
+    uint2 st_r0[NST], st_r1[NST];
+#pragma unroll
+    for (int q = 0; q < NST; ++q) {
+        const int i = tid + q * kBlock;
+        st_w0[q] = st_w1[q] = 0ull;
+        st_r0[q] = st_r1[q] = make_uint2(0u, 0u);
+        if (i < nstage) {
+            const int64_t pi = (one_range || i <= kBlock) ? p0 + i : p0 + d.ncz + (i - kBlock - 1);
+            if (pi < d.P) {
+                const int64_t ui = x * d.P + pi;
+                st_w0[q] = bits[ui];
+                st_w1[q] = bits[ui + d.P];
+                st_r0[q] = rec[ui];  // only entries of units that own vertices are meaningful
+                st_r1[q] = rec[ui + d.P];
+            }
         }
     }
     // faces of the chunks before this tile's chunk (summed by the whole block)
+    u32 cs = 0;
     {
         const int64_t mychunk = (x / a.xw) * a.tpp + tile;
-        u32 cs = 0;
         for (int64_t i = tid; i < mychunk; i += kBlock) cs += a.chunk_sum[i];
+    }
+    if (my_tris == 0u) return;  // nothing to emit here (block-uniform; most tiles of a sparse field)
+#pragma unroll
+    for (int q = 0; q < NST; ++q) {
+        const int i = tid + q * kBlock;
+        if (i < nstage) {
+            s_w[0][i] = st_w0[q];
+            s_w[1][i] = st_w1[q];
+            s_r[0][i] = st_r0[q];
+            s_r[1][i] = st_r1[q];
+        }
+    }
+    {
         cs = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum(cs), 63);
         if (lane == 0) s_tmp[wave] = cs;
     }
@@ -947,8 +970,6 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
         }
     }
 }
-
-#include "faces_walk.inc"
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -1145,25 +1166,15 @@ bool mailbox_wait(const void* ws, u64* nv, u64* nf, u64* flags) {
     return true;
 }
 
-// the face launch: `nface_tiles` > 0 emits triangles (else the launch consists of the compaction blocks only)
+// the face launch: with `faces_here` one block per face tile, else the compaction blocks only
 void launch_faces(const Dims& d, const Ws& w, const u64* bits, const uint2* rec, const FaceArgs& a, const CompactArgs& cp,
                   u64* hdr, int32_t* faces, int64_t capf, bool faces_here, hipStream_t st) {
-    if (env_int("P3D_FACES_OLD", 0)) {
-        const dim3 fgrid((u32)((faces_here ? w.nb_f : 0) + cp.nblocks));
-        if (d.ncz <= 32)
-            hipLaunchKernelGGL(k_faces<32>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
-        else
-            hipLaunchKernelGGL(k_faces<256>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
-        return;
-    }
-    const FaceLayout L = make_face_layout(d);
-    int xs = env_int("P3D_FACE_XS", 2);
-    if (xs < 1) xs = 1;
-    while (xs > 1 && (w.xw % xs) != 0) --xs;   // a segment must lie inside one count chunk
-    const int64_t nseg = d.rx > 1 ? (d.rx - 1 + xs - 1) / xs : 0;
-    const dim3 fgrid((u32)((faces_here ? nseg * w.tpp : 0) + cp.nblocks));
+    const dim3 fgrid((u32)((faces_here ? w.nb_f : 0) + cp.nblocks));
     if (fgrid.x == 0) return;
-    hipLaunchKernelGGL(k_faces_walk, fgrid, dim3(kBlock), (size_t)L.total, st, bits, rec, d, a, cp, L, xs, hdr, faces, capf);
+    if (d.ncz <= 32)
+        hipLaunchKernelGGL(k_faces<32>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
+    else
+        hipLaunchKernelGGL(k_faces<256>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
 }
 
 template <typename T>
