@@ -162,6 +162,7 @@ def main():
     else:
         from primitive3d_amd.slab import SlabExtractor
         ex = SlabExtractor(shape, rank, world, dev)
+        ex.trace = args.stages
         ex.fill_local(lambda x0, x1: perlin_grid(shape, period=64, seed=0, device=dev, x0=x0, x1=x1))
 
         def step():
@@ -265,6 +266,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(grid, thresh, lower, upper, out_v, out_f)
         print(json.dumps(line))
+    if world > 1 and args.stages:
+        # per-phase GPU time of the LAST step on every rank (halo wait, all-gather, record exchange, ...): what the first
+        # real multi-GPU run needs to be diagnosable
+        print(f"rank {rank} phases (ms):", {k: round(v, 4) for k, v in ex.phase_times_ms().items()}, file=sys.stderr)
     if world > 1:
         dist.destroy_process_group()
 

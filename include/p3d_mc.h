@@ -47,15 +47,15 @@ extern "C" {
 #define P3D_EINVAL (-1)   /* bad argument (null pointer, dims < 1, unknown dtype) */
 #define P3D_ERANGE (-2)   /* problem too large for int32 vertex ids / workspace math */
 #define P3D_EHIP (-3)     /* a HIP runtime call failed */
-#define P3D_ECAPACITY (-4) /* outputs did not fit the capacity given to p3d_mc_emit */
 
 /* Slab description for multi-GPU runs (axis-0 slabs, one halo plane).
- * A single-GPU call uses p3d_mc_slab_whole(). */
+ * A single-GPU call passes slab = NULL. */
 typedef struct p3d_mc_slab {
     int32_t halo_last_plane; /* 1: plane rx-1 of `grid` is a halo copy of the next rank's first
                                 plane: its in-plane (axis 1/2) edges are owned by that rank, so no
-                                vertices are emitted for them and their index records are imported
-                                with p3d_mc_import_halo_records. */
+                                vertices are emitted for them; their index records are imported by writing
+                                what the owner exported (p3d_mc_export_plane_records) to the location
+                                p3d_mc_plane_records returns for plane rx-1. */
     int32_t part;            /* p3d_mc_extract_fused only.  0: the whole slab in one call.
                                 1: stream planes [0, split_plane) and return (no finalize, no face pass) -- lets
                                    the interior run while the halo plane is still in flight;
@@ -82,7 +82,8 @@ typedef struct p3d_mc_slab {
 } p3d_mc_slab;
 
 /* Bytes of device scratch p3d_mc_count / p3d_mc_emit need for an [rx,ry,rz] grid.
- * Replaces: `vertex_grids` + `counters` (marching_cubes.cu:229-230, 257-259); 0.25 B/voxel + O(1)
+ * Replaces: `vertex_grids` + `counters` (marching_cubes.cu:229-230, 257-259); about 0.31 B/voxel
+ * (1 bit/voxel of sign words, 8 B per 64-voxel unit of vertex-id records, 4 B per unit of counts) + O(1)
  * instead of 12 B/voxel. */
 int p3d_mc_workspace_bytes(int64_t rx, int64_t ry, int64_t rz, size_t* bytes);
 
@@ -98,9 +99,13 @@ int p3d_mc_count(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz
  * a pinned, host-coherent mailbox slot as soon as they are known and this call polls the slot, so it returns
  * while the remaining kernels of the call may still be running (results are complete in stream order).  Falls
  * back to a 24-byte copy + hipStreamSynchronize when the mailbox is unavailable (P3D_NO_MAILBOX=1, no pinned
- * memory, slot recycled by 64 newer calls).  num_faces is triangles, not indices.  scratch_overflow (nullable) is
- * set to 1 when the scratch buffer handed to p3d_mc_extract_fused was too small for some output region (the
- * vertex buffer is then incomplete and p3d_mc_emit must be used to rewrite it; ids and counts stay valid). */
+ * memory, slot recycled by 64 newer calls).  num_faces is triangles, not indices.  scratch_overflow (nullable)
+ * receives two flags of the last p3d_mc_extract_fused:
+ *   bit 0  the scratch buffer was too small for some output region: the vertex buffer is incomplete and
+ *          p3d_mc_emit must be used to rewrite it (ids and counts stay valid);
+ *   bit 1  one of the 32 regions received more than 2^26 vertices: the ids handed out by the one-pass call are
+ *          ambiguous (they are region * 2^26 + slot).  The COUNTS are still right; the caller must renumber with
+ *          p3d_mc_count (dense ids by prefix scan) and then call p3d_mc_emit. */
 int p3d_mc_read_counts(const void* ws, int64_t* num_vertices, int64_t* num_faces, int32_t* scratch_overflow,
                        void* stream);
 
@@ -108,8 +113,8 @@ int p3d_mc_read_counts(const void* ws, int64_t* num_vertices, int64_t* num_faces
  * write vertices [V,3] f32 already mapped to the bounding box (v * scale + lower, scale as in
  * :293-297 including the upper[2]-lower[1] term of :295) and faces [F,3] i32.  Must follow a
  * p3d_mc_count on the same grid/ws.  cap_vertices/cap_faces are the capacities of the two buffers
- * in elements (rows); nothing is written past them and P3D_ECAPACITY is NOT detected here (the
- * caller compares the counts).  vertex_keys (nullable) receives per-vertex edge keys
+ * in elements (rows); nothing is written past them, and a capacity that is too small is not an error
+ * here (the caller compares the counts it read with the capacities it gave).  vertex_keys (nullable) receives per-vertex edge keys
  * voxel_linear*3+axis (int64, debug/parity output, local slab indexing). */
 int p3d_mc_emit(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz, float thresh,
                 const float lower[3], const float upper[3], const int64_t full_res[3],

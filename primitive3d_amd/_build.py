@@ -18,11 +18,26 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 
-def _stale(out: Path, deps) -> bool:
-    if not out.exists():
+def _digest(deps, extra="") -> str:
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for d in deps:
+        h.update(Path(d).name.encode())
+        h.update(Path(d).read_bytes())
+    return h.hexdigest()
+
+
+def _stale(out: Path, deps, extra="") -> bool:
+    """An artefact is current when the stamp next to it holds the digest of its sources (mtimes mean nothing after a
+    checkout; the stamp travels with the .so in the gpurun snapshot)."""
+    stamp = out.with_name(out.name + ".stamp")
+    if not out.exists() or not stamp.exists():
         return True
-    t = out.stat().st_mtime
-    return any(Path(d).stat().st_mtime > t for d in deps)
+    return stamp.read_text().strip() != _digest(deps, extra)
+
+
+def _write_stamp(out: Path, deps, extra=""):
+    out.with_name(out.name + ".stamp").write_text(_digest(deps, extra) + "\n")
 
 
 def capi_path() -> Path:
@@ -45,6 +60,7 @@ def build_capi(force: bool = False, verbose: bool = False) -> Path:
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+        _write_stamp(out, deps)
     return out
 
 
@@ -68,6 +84,7 @@ def build_pybind(force: bool = False, verbose: bool = False) -> Path:
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+        _write_stamp(out, deps)
     return out
 
 

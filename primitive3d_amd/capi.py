@@ -90,20 +90,31 @@ def _stream_ptr(t):
     return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+def _on_device_of(t):
+    """The library keys its per-device state (cursor ring, result mailbox) by the CURRENT device: make the tensor's
+    device current around every call, as the pybind adapter does with a device guard."""
+    import torch
+    return torch.cuda.device(t.device)
+
+
 def count(grid, thresh, ws, slab=None):
     """p3d_mc_count on a contiguous device tensor [rx,ry,rz]."""
     assert grid.is_cuda and grid.is_contiguous() and grid.dim() == 3
     rx, ry, rz = grid.shape
-    _check(lib().p3d_mc_count(c_void_p(grid.data_ptr()), _dtype_code(grid), rx, ry, rz, c_float(thresh),
-                              byref(slab) if slab is not None else None, c_void_p(ws.data_ptr()),
-                              _stream_ptr(grid)), "p3d_mc_count")
+    with _on_device_of(grid):
+        _check(lib().p3d_mc_count(c_void_p(grid.data_ptr()), _dtype_code(grid), rx, ry, rz, c_float(thresh),
+                                  byref(slab) if slab is not None else None, c_void_p(ws.data_ptr()),
+                                  _stream_ptr(grid)), "p3d_mc_count")
 
 
 def read_counts(ws, with_flags=False):
     v, f, o = c_int64(0), c_int64(0), c_int32(0)
-    _check(lib().p3d_mc_read_counts(c_void_p(ws.data_ptr()), byref(v), byref(f), byref(o), _stream_ptr(ws)),
-           "p3d_mc_read_counts")
-    return (v.value, f.value, bool(o.value)) if with_flags else (v.value, f.value)
+    with _on_device_of(ws):
+        _check(lib().p3d_mc_read_counts(c_void_p(ws.data_ptr()), byref(v), byref(f), byref(o), _stream_ptr(ws)),
+               "p3d_mc_read_counts")
+    # flags: bit 0 = a scratch region overflowed (rewrite the vertices with emit), bit 1 = a region outgrew its 2^26
+    # ids (renumber with count, then emit) -- include/p3d_mc.h
+    return (v.value, f.value, int(o.value)) if with_flags else (v.value, f.value)
 
 
 def emit(grid, thresh, lower, upper, ws, vertices, faces, vertex_keys=None, slab=None, full_res=None):
@@ -113,13 +124,14 @@ def emit(grid, thresh, lower, upper, ws, vertices, faces, vertex_keys=None, slab
     fr = (c_int64 * 3)(*[int(v) for v in full_res]) if full_res is not None else None
     capv = vertices.shape[0] if vertices is not None else 0
     capf = faces.shape[0] if faces is not None else 0
-    _check(lib().p3d_mc_emit(c_void_p(grid.data_ptr()), _dtype_code(grid), rx, ry, rz, c_float(thresh),
-                             byref(lo), byref(up), byref(fr) if fr is not None else None,
-                             byref(slab) if slab is not None else None, c_void_p(ws.data_ptr()),
-                             c_void_p(vertices.data_ptr()) if capv else None, capv,
-                             c_void_p(faces.data_ptr()) if capf else None, capf,
-                             c_void_p(vertex_keys.data_ptr()) if vertex_keys is not None and capv else None,
-                             _stream_ptr(grid)), "p3d_mc_emit")
+    with _on_device_of(grid):
+        _check(lib().p3d_mc_emit(c_void_p(grid.data_ptr()), _dtype_code(grid), rx, ry, rz, c_float(thresh),
+                                 byref(lo), byref(up), byref(fr) if fr is not None else None,
+                                 byref(slab) if slab is not None else None, c_void_p(ws.data_ptr()),
+                                 c_void_p(vertices.data_ptr()) if capv else None, capv,
+                                 c_void_p(faces.data_ptr()) if capf else None, capf,
+                                 c_void_p(vertex_keys.data_ptr()) if vertex_keys is not None and capv else None,
+                                 _stream_ptr(grid)), "p3d_mc_emit")
 
 
 def profile_enable(mode: int):
@@ -153,13 +165,15 @@ def extract_fused_raw(grid, thresh, lower, upper, ws, vertices, faces, slab=None
     fr = (c_int64 * 3)(*[int(v) for v in full_res]) if full_res is not None else None
     capv = vertices.shape[0] if vertices is not None else 0
     capf = faces.shape[0] if faces is not None else 0
-    _check(lib().p3d_mc_extract_fused(c_void_p(grid.data_ptr()), _dtype_code(grid), rx, ry, rz, c_float(thresh),
-                                      byref(lo), byref(up), byref(fr) if fr is not None else None,
-                                      byref(slab) if slab is not None else None, c_void_p(ws.data_ptr()),
-                                      c_void_p(vertices.data_ptr()) if capv else None, capv,
-                                      c_void_p(scratch.data_ptr()) if capv else None, scratch.shape[0] if capv else 0,
-                                      c_void_p(faces.data_ptr()) if capf else None, capf, _stream_ptr(grid)),
-           "p3d_mc_extract_fused")
+    with _on_device_of(grid):
+        _check(lib().p3d_mc_extract_fused(c_void_p(grid.data_ptr()), _dtype_code(grid), rx, ry, rz, c_float(thresh),
+                                          byref(lo), byref(up), byref(fr) if fr is not None else None,
+                                          byref(slab) if slab is not None else None, c_void_p(ws.data_ptr()),
+                                          c_void_p(vertices.data_ptr()) if capv else None, capv,
+                                          c_void_p(scratch.data_ptr()) if capv else None,
+                                          scratch.shape[0] if capv else 0,
+                                          c_void_p(faces.data_ptr()) if capf else None, capf, _stream_ptr(grid)),
+               "p3d_mc_extract_fused")
 
 
 def debug_layout(rx, ry, rz):
@@ -183,6 +197,9 @@ def extract_fused(grid, thresh, lower=None, upper=None, cap_vertices=None, cap_f
     extract_fused_raw(grid, thresh, lower, upper, ws, verts, faces)
     nv, nf, over = read_counts(ws, with_flags=True)
     if nv > capv or nf > capf or over:
+        if over & 2:  # ambiguous one-pass ids: dense ids by the counting call
+            count(grid, thresh, ws)
+            nv, nf = read_counts(ws)
         verts = torch.empty((nv, 3), dtype=torch.float32, device=grid.device)
         faces = torch.empty((nf, 3), dtype=torch.int32, device=grid.device)
         emit(grid, thresh, lower, upper, ws, verts, faces)
@@ -199,8 +216,10 @@ def plane_records(ws, rx, ry, rz, plane):
 
 def export_plane_records(ws, rx, ry, rz, plane, out):
     """Dense vertex-id records of one plane -> `out` (uint8 tensor of bytes_per_plane bytes)."""
-    _check(lib().p3d_mc_export_plane_records(c_void_p(ws.data_ptr()), rx, ry, rz, plane, c_void_p(out.data_ptr()),
-                                             _stream_ptr(ws)), "p3d_mc_export_plane_records")
+    with _on_device_of(ws):
+        _check(lib().p3d_mc_export_plane_records(c_void_p(ws.data_ptr()), rx, ry, rz, plane,
+                                                 c_void_p(out.data_ptr()), _stream_ptr(ws)),
+               "p3d_mc_export_plane_records")
     return out
 
 

@@ -34,8 +34,9 @@ struct CapHint {
     int64_t nv, nf;
     int slack_q;  // headroom of every scratch region in quarters (5 = 1.25x); grows after a region overflow
 };
-std::map<CapKey, CapHint> g_cap_hint;
+std::map<CapKey, CapHint> g_cap_hint;   // at most kMaxHints shapes; when full, the map is dropped (hints are only hints)
 std::mutex g_cap_mu;
+constexpr size_t kMaxHints = 256;
 
 void check_rc(int rc, const char* what) {
     TORCH_CHECK(rc == P3D_OK, what, " failed (", rc, "): ", p3d_last_error());
@@ -73,6 +74,13 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
         const char* m = std::getenv("P3D_MC_MODE");
         return m && std::string(m) == "exact";
     }();
+    // P3D_MC_EXACT_ALLOC=1: the returned tensors always own exactly V / F rows (a copy when the capacity guess was
+    // larger), like the reference's torch::zeros({V,3}) (marching_cubes.cu:260-263).  Default: rows [0, V) of a buffer
+    // that may be up to 1/8 + 4096 rows longer (no copy of 190 MB per 512^3 call).
+    static const bool exact_alloc = [] {
+        const char* m = std::getenv("P3D_MC_EXACT_ALLOC");
+        return m && *m && std::string(m) != "0";
+    }();
     static const bool host_trace = std::getenv("P3D_HOST_TRACE") != nullptr;
     auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_in = host_trace ? now_us() : 0.0;
@@ -80,7 +88,7 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     // One streaming pass into buffers of the given capacities (0,0 = count only).  The vertex scratch is cut into
     // 32 independently filled regions: `slack` is the headroom per region, and every region can hold 8192 rows
     // because a small output may come from very few wave-planes.  Returns true when everything fitted.
-    bool region_overflow = false;
+    bool region_overflow = false, id_overflow = false;
     auto run_pass = [&](int64_t capv, int64_t capf, int64_t slack_num, int64_t slack_den) {
         Tensor scratch;
         int64_t scratch_rows = 0;
@@ -98,7 +106,8 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
                  "p3d_mc_extract_fused");
         int32_t overflow = 0;
         check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, &overflow, stream), "p3d_mc_read_counts");
-        region_overflow = overflow != 0 && nv <= capv;  // the total fitted, the split over the regions did not
+        region_overflow = (overflow & 1) != 0 && nv <= capv;  // the total fitted, the split over the regions did not
+        id_overflow = (overflow & 2) != 0;                     // a region outgrew its id space: renumber (below)
         return nv <= capv && nf <= capf && !overflow;
     };
 
@@ -125,6 +134,7 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     {
         // a field whose vertices are spread unevenly over the 32 regions gets more headroom per region next time
         std::lock_guard<std::mutex> g(g_cap_mu);
+        if (g_cap_hint.size() >= kMaxHints && g_cap_hint.find(key) == g_cap_hint.end()) g_cap_hint.clear();
         g_cap_hint[key] = {nv, nf, region_overflow ? std::min(2 * slack_q, 32) : slack_q};
     }
     if (host_trace) {
@@ -136,8 +146,14 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     }
     if (!ok || exact_mode) {
         const int64_t ev = nv, ef = nf;  // exact sizes are known now
-        ok = run_pass(ev, ef, std::max(8, 2 * slack_q), 4);
+        ok = !id_overflow && run_pass(ev, ef, std::max(8, 2 * slack_q), 4);
         if (!ok) {
+            // a region numbered more than 2^26 vertices: the one-pass ids are ambiguous -> dense ids by the
+            // counting call (include/p3d_mc.h: p3d_mc_read_counts, bit 1)
+            if (id_overflow) {
+                check_rc(p3d_mc_count(grid, P3D_F32, rx, ry, rz, thresh, nullptr, ws.data_ptr(), stream), "p3d_mc_count");
+                check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, nullptr, stream), "p3d_mc_read_counts");
+            }
             // pathological region imbalance: the gather emitter writes by vertex id and cannot overflow
             vertices = torch::empty({nv, 3}, vopt);
             faces = torch::empty({nf, 3}, fopt);
@@ -150,9 +166,14 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
         if (nf == 0) faces = torch::empty({0, 3}, fopt);
         return {vertices, faces};
     }
-    // exact-size results: a view when the buffer is mostly used, a copy when the guess was generous
-    vertices = (2 * nv >= capv) ? vertices.narrow(0, 0, nv) : vertices.narrow(0, 0, nv).clone();
-    faces = (2 * nf >= capf) ? faces.narrow(0, 0, nf) : faces.narrow(0, 0, nf).clone();
+    // exact-size results: the first V / F rows of the buffers; a copy when the guess was generous (the first call on a
+    // shape) or when exact allocations were asked for
+    auto fit = [&](Tensor& t, int64_t n, int64_t cap) {
+        if (n == cap) return;
+        t = (!exact_alloc && 2 * n >= cap) ? t.narrow(0, 0, n) : t.narrow(0, 0, n).clone();
+    };
+    fit(vertices, nv, capv);
+    fit(faces, nf, capf);
     return {vertices, faces};
 }
 
@@ -163,10 +184,14 @@ void save_mesh_as_ply(const std::string filename, Tensor vertices, Tensor faces,
     TORCH_CHECK(vertices.is_contiguous(), "vertices must be contiguous");
     TORCH_CHECK(faces.is_contiguous(), "faces must be contiguous");
     TORCH_CHECK(colors.is_contiguous(), "colors must be contiguous");
-    TORCH_CHECK(colors.scalar_type() == torch::kUInt8, "colors must be uint8");
-    vertices = vertices.to(torch::kCPU).to(torch::kFloat).contiguous();
-    faces = faces.to(torch::kCPU).to(torch::kInt).contiguous();
-    colors = colors.to(torch::kCPU).contiguous();
+    // the reference reads the three buffers with data_ptr<float>() / data_ptr<int32_t>() / data_ptr<uint8_t>()
+    // (marching_cubes.cu:334-347), which throws on any other dtype: no silent conversion here either
+    TORCH_CHECK(vertices.scalar_type() == torch::kFloat, "expected scalar type Float but found ", vertices.scalar_type());
+    TORCH_CHECK(faces.scalar_type() == torch::kInt, "expected scalar type Int but found ", faces.scalar_type());
+    TORCH_CHECK(colors.scalar_type() == torch::kByte, "expected scalar type Byte but found ", colors.scalar_type());
+    vertices = vertices.to(torch::kCPU);
+    faces = faces.to(torch::kCPU);
+    colors = colors.to(torch::kCPU);
     const int64_t nv = vertices.size(0), nf = faces.size(0);
 
     std::ofstream ply(filename, std::ios::out | std::ios::binary);

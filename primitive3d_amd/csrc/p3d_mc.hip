@@ -467,6 +467,7 @@ struct CompactArgs {
     const u32* chunk_sum;  // block 0 adds the chunk sums up to F
     int nchunks;
     const u64* cursors;    // the call's cursor block
+    u32 id_limit;          // vertices a region may number (2^26: ids are region * 2^26 + slot); beyond it ids alias
 };
 typedef float F4U __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access at 4-byte alignment
 typedef float F4A __attribute__((ext_vector_type(4)));
@@ -487,12 +488,14 @@ __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr
         }
         if (blockIdx.x == 0 && c.finish) {
             const u64 over = __ballot(cur > (u64)(c.scratch ? c.store_rows : c.region_rows));
+            const u64 wrap = __ballot(cur > (u64)c.id_limit);   // a region outgrew its id space: ids are ambiguous
+            const u64 flags = (over ? 1ull : 0ull) | (wrap ? 2ull : 0ull);
             if (lane < kRegions) hdr[H_PREFIX + lane] = inc - cur;
             if (lane == kRegions - 1) {
                 hdr[H_V] = inc;
-                hdr[H_FLAGS] = over ? 1ull : 0ull;
+                hdr[H_FLAGS] = flags;
                 hdr[H_RECFORM] = 1ull;
-                mb_publish_v(mb, seq, inc, over ? 1ull : 0ull);
+                mb_publish_v(mb, seq, inc, flags);
             }
         }
     }
@@ -677,7 +680,8 @@ __global__ void __launch_bounds__(kBlock) k_face_total(const u32* __restrict__ c
 // path wants them before the face count: the all-gather of V and the export of the first plane's records can then
 // travel while the counting and compaction kernels run.  (The finishing block of the k_faces launch writes the
 // same values again and reports to the host.)
-__global__ void k_early_header(u64* __restrict__ hdr, const u64* __restrict__ cursors, u32 rows_per_region) {
+__global__ void k_early_header(u64* __restrict__ hdr, const u64* __restrict__ cursors, u32 rows_per_region,
+                               u32 id_limit) {
     const int lane = threadIdx.x;
     const u64 cur = lane < kRegions ? cursors[lane * kCursorStride] : 0ull;
     u64 inc = cur;
@@ -687,10 +691,11 @@ __global__ void k_early_header(u64* __restrict__ hdr, const u64* __restrict__ cu
         if (lane >= o) inc += tt;
     }
     const u64 over = __ballot(cur > (u64)rows_per_region);
+    const u64 wrap = __ballot(cur > (u64)id_limit);
     if (lane < kRegions) hdr[H_PREFIX + lane] = inc - cur;
     if (lane == kRegions - 1) {
         hdr[H_V] = inc;
-        hdr[H_FLAGS] = over ? 1ull : 0ull;
+        hdr[H_FLAGS] = (over ? 1ull : 0ull) | (wrap ? 2ull : 0ull);
         hdr[H_RECFORM] = 1ull;
     }
 }
@@ -1008,7 +1013,8 @@ enum { ST_CLASSIFY = 0, ST_UNIT_COUNTS, ST_SCAN_V, ST_UNIT_RECORDS, ST_FACES_COU
        ST_EMIT_FACES, ST_FUSED, ST_FINALIZE, ST_FUSED_INTERIOR, ST_N };
 const char* const k_stage_names[ST_N] = {"k_classify",    "k_unit_counts", "k_scan_blocks(v)", "k_unit_records",
                                          "k_face_count_walk", "k_face_total", "k_emit_vertices", "k_faces",
-                                         "k_fused", "k_finalize(prefix+fix_records+compact)", "k_fused(interior part)"};
+                                         "k_fused", "(unused)", "k_fused(interior part)"};
+// (measurement hooks: one global set of events, NOT thread-safe -- meant for a single benchmarking thread)
 int g_prof_mode = 0;  // 0 off, 1 dominant kernel only (k_classify), 2 every stage
 hipEvent_t g_ev[ST_N][2];
 bool g_ev_made = false;
@@ -1160,9 +1166,15 @@ bool mailbox_wait(const void* ws, u64* nv, u64* nf, u64* flags) {
             std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return false;
         __builtin_ia32_pause();
     }
-    *nv = slot[1];
-    *flags = slot[2];
-    *nf = slot[4];
+    // seqlock: a call 64 sequence numbers newer (another thread or stream) may have recycled the slot between the
+    // check above and these loads -- re-check the two sequence words after the payload
+    const u64 v1 = __atomic_load_n(&slot[1], __ATOMIC_ACQUIRE), v2 = __atomic_load_n(&slot[2], __ATOMIC_ACQUIRE);
+    const u64 v4 = __atomic_load_n(&slot[4], __ATOMIC_ACQUIRE);
+    if (__atomic_load_n(&slot[0], __ATOMIC_ACQUIRE) != seq || __atomic_load_n(&slot[3], __ATOMIC_ACQUIRE) != seq)
+        return false;
+    *nv = v1;
+    *flags = v2;
+    *nf = v4;
     return true;
 }
 
@@ -1212,7 +1224,7 @@ int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3
     }
     if (w.nchunks > 0) {
         StageTimer tm(ST_FACES_COUNT, st);
-        const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr};
+        const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr, 1u << 26};
         hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)w.nchunks), dim3(kBlock), 0, st, bits, d, w.tpp, w.xw, csum,
                            woff, (u32*)(ws + w.tile_tris), none, hdr);
     }
@@ -1250,7 +1262,7 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
                          slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw,
                          (const u32*)(ws + w.chunk_sum), (const u32*)(ws + w.wave_off),
                          (const u32*)(ws + w.tile_tris), nullptr, nullptr, 0};
-        const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr};
+        const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr, 1u << 26};
         launch_faces(d, w, bits, rec, a, none, hdr, faces, capf, true, st);
     }
     HIP_TRY(hipGetLastError());
@@ -1346,6 +1358,8 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     // unambiguous even when a region outgrows its share of the scratch buffer); readers make them dense on the fly.
     // Storage is store_rows rows per region; without a scratch buffer nothing is stored (pure count + ids).
     const u32 region_rows = 1u << 26;
+    // (test hook: P3D_TEST_ID_LIMIT pretends the id space of a region is smaller, to reach the callers' fallback)
+    const u32 id_limit = (u32)std::min<int64_t>(region_rows, std::max(1, env_int("P3D_TEST_ID_LIMIT", 1 << 26)));
     const u32 store_rows = scratch ? (u32)std::min<int64_t>(scratch_rows / kRegions, (int64_t)region_rows) : 0u;
     const int part = slab ? slab->part : 0;
     // parts (p3d_mc_slab.part): 0 everything; 1 planes [0, split) only; 2 planes [split, rx) + finalize;
@@ -1375,7 +1389,8 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
                           timed ? g_ev[stage][0] : nullptr, timed ? g_ev[stage][1] : nullptr, st);
     }
     if (part == 3)
-        hipLaunchKernelGGL(k_early_header, dim3(1), dim3(64), 0, st, hdr, cursors, scratch ? store_rows : region_rows);
+        hipLaunchKernelGGL(k_early_header, dim3(1), dim3(64), 0, st, hdr, cursors, scratch ? store_rows : region_rows,
+                           id_limit);
     if (part == 1 || part == 3) {  // a later call finalizes
         HIP_TRY(hipGetLastError());
         return P3D_OK;
@@ -1396,7 +1411,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     if (w.nchunks > 0 && part != 5) {
         StageTimer tm(ST_FACES_COUNT, st);
         const CompactArgs cpe{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, early * kRegions, 0, nparts, 0,
-                              csum, (int)w.nchunks, cursors};
+                              csum, (int)w.nchunks, cursors, id_limit};
         hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)(w.nchunks + cpe.nblocks)), dim3(kBlock), 0, st, bits,
                            d, w.tpp, w.xw, csum, woff, (u32*)(ws + w.tile_tris), cpe, hdr);
     }
@@ -1410,7 +1425,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
                      slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw,
                      csum, woff, (const u32*)(ws + w.tile_tris), cursors, mb, seq};
     const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, (nparts - early) * kRegions, early,
-                         nparts, part == 5 ? 0 : 1, csum, (int)w.nchunks, cursors};
+                         nparts, part == 5 ? 0 : 1, csum, (int)w.nchunks, cursors, id_limit};
     StageTimer tm(ST_EMIT_FACES, st);
     launch_faces(d, w, bits, rec, a, cp, hdr, faces, capf, faces_here, st);
     HIP_TRY(hipGetLastError());
@@ -1457,7 +1472,7 @@ int p3d_mc_read_counts(const void* ws, int64_t* num_vertices, int64_t* num_faces
     }
     *num_vertices = (int64_t)h[H_V];
     *num_faces = (int64_t)h[H_T];
-    if (scratch_overflow) *scratch_overflow = (int32_t)(h[H_FLAGS] & 1ull);
+    if (scratch_overflow) *scratch_overflow = (int32_t)(h[H_FLAGS] & 3ull);
     if (h[H_V] > 0x7fffffffull || h[H_T] > 0x7fffffffull)
         return fail(P3D_ERANGE, "vertex/face count exceeds int32 indexing%s");
     return P3D_OK;

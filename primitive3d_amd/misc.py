@@ -7,6 +7,14 @@ from time import perf_counter
 _HAS_FLOAT_FIELD = re.compile(r"\{:[^}]*\df\}")
 
 
+class TimerError(Exception):
+    """Raised when a stopped timer is queried (same name and role as prim3d/misc/utils.py:34-38)."""
+
+    def __init__(self, message="timer is not running"):
+        self.message = message
+        super().__init__(message)
+
+
 class Timer:
     """Context manager / stopwatch.  `print_tmpl` without a `{:.nf}` field gets ` {:.3f}` appended."""
 
@@ -33,7 +41,7 @@ class Timer:
 
     def _require_running(self):
         if self._origin is None:
-            raise RuntimeError("timer is not running")
+            raise TimerError("timer is not running")
 
     def since_start(self):
         self._require_running()

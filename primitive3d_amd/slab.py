@@ -96,6 +96,9 @@ class HipBackend:
         grid, thresh, lower, upper, full_res, ws, _ = self._state
         verts = self._verts
         nv, nf, over = c.read_counts(ws, with_flags=True)
+        if over & 2:
+            raise OverflowError("a vertex region of this slab numbered more than 2^26 vertices (include/p3d_mc.h, "
+                                "p3d_mc_read_counts bit 1): use more ranks / thinner slabs")
         overflow = nv > verts.shape[0] or over
         if overflow:
             verts = torch.empty((nv, 3), dtype=torch.float32, device=self.device)
@@ -193,9 +196,16 @@ class SlabResult:
     device it is computed from them on first access (a device-to-host copy, i.e. a synchronisation).
     counts: (V, F) of every rank -- host path only."""
 
-    def __init__(self, vertices, faces, vertex_base=None, counts=None, rank=None, rank_counts=None):
+    def __init__(self, vertices, faces, vertex_base=None, counts=None, rank=None, rank_counts=None, check=None):
         self.vertices, self.faces = vertices, faces
         self._base, self.counts, self._rank, self._rank_counts = vertex_base, counts, rank, rank_counts
+        self._check = check
+
+    def check_total(self):
+        """Device path: wait for this extraction's gathered vertex counts and raise OverflowError if their sum does not
+        fit int32 face indices (the extractor does the same, without waiting, when its next extraction starts)."""
+        if self._check is not None:
+            self._check()
 
     @property
     def vertex_base(self) -> int:
@@ -218,6 +228,23 @@ class SlabExtractor:
         rx, ry, rz = self.shape
         self.grid = torch.empty((self.n + (1 if self.has_halo else 0), ry, rz), dtype=dtype, device=device)
         self.backend = backend if backend is not None else HipBackend(device)
+        # phase tracing (bench.py --stages): events on the current stream at the phase boundaries of extract(); the
+        # span between two marks is the GPU time of what was enqueued between them, waits on collectives included
+        self.trace = False
+        self._marks = []
+
+    def _mark(self, name):
+        if self.trace and self.grid.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._marks.append((name, ev))
+
+    def phase_times_ms(self):
+        """{phase: ms} of the last traced extract() (synchronises)."""
+        if len(self._marks) < 2:
+            return {}
+        self._marks[-1][1].synchronize()
+        return {b[0]: a[1].elapsed_time(b[1]) for a, b in zip(self._marks, self._marks[1:])}
 
     # -- data ---------------------------------------------------------------------------------
     def fill_local(self, gen):
@@ -267,6 +294,19 @@ class SlabExtractor:
         faces = self.backend.faces(base, halo_base)
         return SlabResult(self._verts, faces, base, counts)
 
+    def _check_pending_total(self, wait: bool = True):
+        pend = getattr(self, "_pending_total", None)
+        if pend is None:
+            return
+        host, ev = pend
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        self._pending_total = None
+        if int(host.sum()) > 2 ** 31 - 1:
+            raise OverflowError("global vertex count exceeds int32 face indices")
+
     # -- the distributed call -----------------------------------------------------------------
     def extract(self, thresh, lower=None, upper=None) -> SlabResult:
         import torch.distributed as dist
@@ -291,11 +331,15 @@ class SlabExtractor:
                 torch.cuda.synchronize()
 
         # the halo plane travels while the interior planes are already being streamed
+        self._marks = []
+        self._mark("start")
         pre_comm()
         works = shift_to_prev(self.halo_send_buffer(), self.halo_recv_buffer())
         self.phase_interior(thresh, lower, upper)
+        self._mark("interior planes streamed")
         for w in works:
             w.wait()
+        self._mark("halo plane received (wait)")
         if hasattr(self.backend, "faces_from_rank_counts"):
             # device path: V and the id prefixes are in the workspace header as soon as the slab is streamed, so the
             # all-gather of V and the record exchange are enqueued BEFORE the face count / vertex compaction and
@@ -305,15 +349,31 @@ class SlabExtractor:
             be.stream_rest(self.grid, float(thresh), list(lower), list(upper), self.shape, self.x0, self.has_halo)
             rank_counts = torch.empty(self.world, dtype=torch.int64, device=self.grid.device)
             send_buf = self.records_send_buffer()  # (kept referenced until the transfer has completed)
+            self._mark("last planes streamed + record export")
             pre_comm()
             dist.all_gather_into_tensor(rank_counts, be.header_vertex_count())
+            self._mark("all-gather of vertex counts")
             rec_works = shift_to_prev(send_buf, self.records_recv_buffer())
             be.launch_finalize()
+            self._mark("face count + early vertex copy")
             for w in rec_works:
                 w.wait()
+            self._mark("halo records received (wait)")
             del send_buf
             self._nv, self._nf, self._verts, faces = be.finish_on_device(rank_counts, self.rank)
-            return SlabResult(self._verts, faces, rank=self.rank, rank_counts=rank_counts)
+            self._mark("faces + rest of vertex copy")
+            # int32 guard on the GLOBAL vertex total (the host path checks it in phase_faces): the gathered counts live
+            # on the device, so they are copied to pinned memory behind the work already enqueued and looked at when the
+            # next extraction starts or when the caller asks (SlabResult.check_total) -- never a wait inside this call
+            self._check_pending_total()
+            host = torch.empty(self.world, dtype=torch.int64, pin_memory=True) if self.grid.is_cuda else None
+            if host is not None:
+                host.copy_(rank_counts, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._pending_total = (host, ev)
+            return SlabResult(self._verts, faces, rank=self.rank, rank_counts=rank_counts,
+                              check=self._check_pending_total)
         nv, nf = self.phase_extract(thresh, lower, upper)
         mine = torch.tensor([nv, nf], dtype=torch.int64, device=self.grid.device)
         allc = [torch.empty_like(mine) for _ in range(self.world)]

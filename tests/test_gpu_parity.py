@@ -211,3 +211,42 @@ def test_adapter_on_a_row_with_a_nearly_empty_last_z_tile(gpu, built):
     rv, rf, _ = oracle_extract(g, 0.1, [0.0, 0.0, 0.0], [24.0, 40.0, 517.0])
     soup = lambda vv, ff: np.sort(vv[ff.astype(np.int64)].reshape(len(ff), 9).view([("", np.float32)] * 9), axis=0)
     assert np.array_equal(soup(v.cpu().numpy(), f.cpu().numpy()), soup(rv, rf))
+
+
+def test_region_id_space_overflow_falls_back_to_the_counting_call(gpu, built, monkeypatch):
+    """A region that numbers more than 2^26 vertices makes the one-pass ids ambiguous (include/p3d_mc.h,
+    p3d_mc_read_counts bit 1).  P3D_TEST_ID_LIMIT pretends the id space is tiny: the flag must come back, and both the
+    ctypes flow and the pybind adapter must renumber with p3d_mc_count + p3d_mc_emit and still return the exact mesh."""
+    from primitive3d_amd import capi
+    monkeypatch.setenv("P3D_TEST_ID_LIMIT", "16")
+    g, thresh, lower, upper = small_cases()["noise_33x17x200"]
+    t = torch.from_numpy(g).to(gpu)
+    ws = torch.empty(capi.workspace_bytes(*t.shape), dtype=torch.uint8, device=gpu)
+    capi.extract_fused_raw(t, thresh, lower, upper, ws, None, None)
+    nv, nf, flags = capi.read_counts(ws, with_flags=True)
+    assert (nv, nf) == oracle_count(g, thresh) and flags & 2
+    ref = oracle_extract(g, thresh, lower, upper)
+    v, f = capi.extract_fused(t, thresh, lower, upper)
+    soup = lambda vv, ff: np.sort(vv[ff.astype(np.int64)].reshape(len(ff), 9).view([("", np.float32)] * 9), axis=0)
+    assert np.array_equal(soup(v.cpu().numpy(), f.cpu().numpy()), soup(ref[0], ref[1]))
+    v, f = built.libPrim3D.marching_cubes(t, thresh, lower, upper)
+    assert np.array_equal(soup(v.cpu().numpy(), f.cpu().numpy()), soup(ref[0], ref[1]))
+    monkeypatch.delenv("P3D_TEST_ID_LIMIT")
+    capi.extract_fused_raw(t, thresh, lower, upper, ws, None, None)
+    assert capi.read_counts(ws, with_flags=True)[2] == 0
+
+
+def test_ply_of_a_device_resident_extraction(gpu, built, tmp_path):
+    """save_mesh on the CUDA tensors marching_cubes returns (examples/sphere.py:15-17) == the restated reference
+    writer (oracle/ply_oracle.py, marching_cubes.cu:307-352) byte for byte."""
+    from oracle.ply_oracle import reference_ply_bytes
+    from primitive3d_amd.fields import sphere_grid
+    v, f = built.marching_cubes(sphere_grid(64), 0, scale=2.0)
+    assert v.is_cuda and f.is_cuda
+    p = tmp_path / "sphere.ply"
+    built.save_mesh(v, f, filename=p)
+    vn, fn = v.cpu().numpy(), f.cpu().numpy()
+    assert p.read_bytes() == reference_ply_bytes(vn, fn, np.full(vn.shape, 127, np.uint8))
+    colors = (torch.rand(v.shape, device=gpu) * 255).to(torch.uint8)
+    built.libPrim3D.save_mesh_as_ply(str(p), v, f, colors)
+    assert p.read_bytes() == reference_ply_bytes(vn, fn, colors.cpu().numpy())

@@ -1,6 +1,6 @@
 """The multi-GPU call itself (SlabExtractor.extract with the HIP backend: collectives enqueued before the finalize
 kernels, id bases derived on the device from the all-gathered vertex counts) run by TWO processes that share the one
-GPU of the test box, gloo standing in for RCCL as transport.  The merged mesh must equal the oracle's mesh of the whole
+GPU of the test box (2, 3 and 8 processes), gloo standing in for RCCL as transport.  The merged mesh must equal the oracle's mesh of the whole
 grid."""
 import os
 import sys
@@ -32,9 +32,13 @@ def _worker(rank, world, port, out_dir, shape, thresh, lower, upper):
     ex = SlabExtractor(shape, rank, world, dev)
     # (generated on the CPU like the oracle's input: the device generator may differ in the last bit)
     ex.fill_local(lambda x0, x1: perlin_grid(shape, period=12, seed=5, x0=x0, x1=x1).to(dev))
+    ex.trace = True
     for _ in range(2):  # the second call reuses the size hints and the cursor ring
         res = ex.extract(thresh, lower, upper)
     torch.cuda.synchronize()
+    res.check_total()  # the deferred int32 guard of the device path
+    phases = ex.phase_times_ms()
+    assert "faces + rest of vertex copy" in phases and all(t >= 0 for t in phases.values())
     lshape = tuple(ex.grid.shape)
     k = vertex_keys_from_workspace(ex.backend._ws.cpu().numpy(), lshape, res.vertices.shape[0],
                                    capi.debug_layout(*lshape), halo_last_plane=ex.has_halo)
@@ -46,10 +50,11 @@ def _worker(rank, world, port, out_dir, shape, thresh, lower, upper):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_distributed_extract_on_one_gpu(tmp_path, gpu, world):
+@pytest.mark.parametrize("world,shape", [(2, (61, 21, 150)), (3, (61, 21, 150)), (8, (61, 21, 150)),
+                                         (8, (208, 21, 150))])   # 8 ranks: thin slabs, and slabs streamed in two parts
+def test_distributed_extract_on_one_gpu(tmp_path, gpu, world, shape):
     from primitive3d_amd.fields import perlin_grid
-    shape, thresh, lower, upper = (61, 21, 150), 0.02, [0.5, -1.0, 2.0], [3.0, 4.0, 9.0]
+    thresh, lower, upper = 0.02, [0.5, -1.0, 2.0], [3.0, 4.0, 9.0]
     port = 29600 + (os.getpid() % 2000) + world
     mp.spawn(_worker, args=(world, port, str(tmp_path), shape, thresh, lower, upper), nprocs=world, join=True)
     parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]

@@ -108,6 +108,40 @@ def test_ply_writer_bytes(built, tmp_path):
     assert body == expect
 
 
+def test_ply_writer_matches_the_restated_reference_writer(built, tmp_path):
+    """Random mesh through save_mesh (default colours and given colours) == oracle/ply_oracle.py byte for byte."""
+    from oracle.ply_oracle import reference_ply_bytes
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal((257, 3)).astype(np.float32)
+    f = rng.integers(0, 257, size=(511, 3)).astype(np.int32)
+    c = rng.integers(0, 256, size=(257, 3)).astype(np.uint8)
+    p = tmp_path / "a.ply"
+    built.save_mesh(v, f, c, filename=p)
+    assert p.read_bytes() == reference_ply_bytes(v, f, c)
+    built.save_mesh(torch.from_numpy(v), torch.from_numpy(f).long(), filename=str(p))   # wrapper: faces.int(), grey
+    assert p.read_bytes() == reference_ply_bytes(v, f, np.full_like(c, 127))
+
+
+def test_ply_writer_rejects_other_dtypes_like_the_reference(built, tmp_path):
+    """marching_cubes.cu:334-347 reads the buffers with data_ptr<float>() / <int32_t>() / <uint8_t>(): other dtypes
+    raise there, and here (no silent conversion); non-contiguous inputs raise the CHECK_CONTIGUOUS message."""
+    C = built.libPrim3D
+    v = torch.zeros(4, 3)
+    f = torch.zeros(2, 3, dtype=torch.int32)
+    c = torch.zeros(4, 3, dtype=torch.uint8)
+    name = str(tmp_path / "x.ply")
+    with pytest.raises(RuntimeError, match="expected scalar type Float"):
+        C.save_mesh_as_ply(name, v.double(), f, c)
+    with pytest.raises(RuntimeError, match="expected scalar type Int"):
+        C.save_mesh_as_ply(name, v, f.long(), c)
+    with pytest.raises(RuntimeError, match="expected scalar type Byte"):
+        C.save_mesh_as_ply(name, v, f, c.float())
+    with pytest.raises(RuntimeError, match="must be contiguous"):
+        C.save_mesh_as_ply(name, torch.zeros(3, 4).t(), f, c)
+    with pytest.raises(NotImplementedError):
+        built.save_mesh(v, f, filename="mesh.obj")
+
+
 def test_package_surface(built):
     import prim3d
     assert prim3d.ENABLE_OPTIX is False and prim3d.__version__
