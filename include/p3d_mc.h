@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define P3D_MC_ABI_VERSION 4
+#define P3D_MC_ABI_VERSION 5
 
 /* dtype of the scalar field */
 #define P3D_F32 0
@@ -139,6 +139,23 @@ int p3d_mc_extract_fused(const void* grid, int dtype, int64_t rx, int64_t ry, in
                          const p3d_mc_slab* slab, void* ws, float* vertices, int64_t cap_vertices,
                          float* vertex_scratch, int64_t scratch_rows, int32_t* faces, int64_t cap_faces,
                          void* stream);
+
+/* Batched one-pass extraction: `nitems` grids of ONE shape [rx,ry,rz], back to back in memory ([B,rx,ry,rz]
+ * contiguous), extracted by one streaming launch, one counting launch and one face launch for the whole batch -- a
+ * 256^3 grid alone cannot fill 256 CUs, so per-item calls are bound by launch ramp and tail (BASELINE.json config 5:
+ * 32 x 256^3 fp16 density grids).  The reference has no counterpart (its entry rejects 4-D input,
+ * marching_cubes.cu:219); every item gives exactly the mesh p3d_mc_extract_fused gives for it alone:
+ *   vertices  [sum V_b, 3]  item b's rows are [item_offsets[b], item_offsets[b+1])
+ *   faces     [sum F_b, 3]  item b's rows are [item_offsets[B+1+b], item_offsets[B+2+b]), vertex ids LOCAL to the item
+ *   item_offsets            DEVICE memory, 2*(B+1) int64, written by the last launch
+ * Capacities, scratch (32 regions PER ITEM: size it about 1.25x the expected total) and the overflow protocol are
+ * those of p3d_mc_extract_fused: read the totals and flags with p3d_mc_read_counts; if something did not fit, call
+ * again with exact capacities (or fall back to per-item calls).  Workspace: p3d_mc_workspace_bytes_batched. */
+int p3d_mc_workspace_bytes_batched(int64_t nitems, int64_t rx, int64_t ry, int64_t rz, size_t* bytes);
+int p3d_mc_extract_fused_batched(const void* grids, int dtype, int64_t nitems, int64_t rx, int64_t ry, int64_t rz,
+                                 float thresh, const float lower[3], const float upper[3], void* ws, float* vertices,
+                                 int64_t cap_vertices, float* vertex_scratch, int64_t scratch_rows, int32_t* faces,
+                                 int64_t cap_faces, int64_t* item_offsets, void* stream);
 
 /* Test hook: where the sign bitfield (u64 per 64-voxel unit, unit u = (x*ry+y)*ncz + c) and the
  * vertex-id records ({u32 base, u32 offY | offZ<<16} per unit) live inside `ws`, so a test can

@@ -13,7 +13,8 @@ P3D_OK = 0
 # every symbol include/p3d_mc.h declares
 SYMBOLS = ("p3d_mc_abi_version", "p3d_last_error", "p3d_mc_workspace_bytes", "p3d_mc_count",
            "p3d_mc_read_counts", "p3d_mc_emit", "p3d_mc_plane_records", "p3d_mc_export_plane_records", "p3d_mc_profile_enable",
-           "p3d_mc_profile_read", "p3d_mc_profile_stage_name", "p3d_mc_extract_fused", "p3d_mc_debug_layout")
+           "p3d_mc_profile_read", "p3d_mc_profile_stage_name", "p3d_mc_extract_fused", "p3d_mc_debug_layout",
+           "p3d_mc_workspace_bytes_batched", "p3d_mc_extract_fused_batched")
 
 
 class Slab(ctypes.Structure):
@@ -51,6 +52,10 @@ def lib():
         L.p3d_mc_extract_fused.argtypes = [c_void_p, c_int, c_int64, c_int64, c_int64, c_float, POINTER(c_float * 3),
                                            POINTER(c_float * 3), POINTER(c_int64 * 3), POINTER(Slab), c_void_p,
                                            c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]
+        L.p3d_mc_workspace_bytes_batched.argtypes = [c_int64, c_int64, c_int64, c_int64, POINTER(c_size_t)]
+        L.p3d_mc_extract_fused_batched.argtypes = [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_float,
+                                                   POINTER(c_float * 3), POINTER(c_float * 3), c_void_p, c_void_p,
+                                                   c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]
         L.p3d_mc_debug_layout.argtypes = [c_int64, c_int64, c_int64, POINTER(c_size_t), POINTER(c_size_t),
                                           POINTER(c_int64), POINTER(c_int32)]
         L.p3d_mc_profile_enable.argtypes = [c_int]
@@ -174,6 +179,30 @@ def extract_fused_raw(grid, thresh, lower, upper, ws, vertices, faces, slab=None
                                           scratch.shape[0] if capv else 0,
                                           c_void_p(faces.data_ptr()) if capf else None, capf, _stream_ptr(grid)),
                "p3d_mc_extract_fused")
+
+
+def workspace_bytes_batched(nitems, rx, ry, rz) -> int:
+    n = c_size_t(0)
+    _check(lib().p3d_mc_workspace_bytes_batched(nitems, rx, ry, rz, byref(n)), "p3d_mc_workspace_bytes_batched")
+    return n.value
+
+
+def extract_fused_batched_raw(grids, thresh, lower, upper, ws, vertices, scratch, faces, item_offsets):
+    """p3d_mc_extract_fused_batched on a contiguous [B, rx, ry, rz] device tensor (f32 or f16); item_offsets is a
+    [2*(B+1)] int64 device tensor."""
+    assert grids.is_cuda and grids.is_contiguous() and grids.dim() == 4
+    B, rx, ry, rz = grids.shape
+    lo = (c_float * 3)(*[float(v) for v in lower])
+    up = (c_float * 3)(*[float(v) for v in upper])
+    capv = vertices.shape[0] if vertices is not None else 0
+    capf = faces.shape[0] if faces is not None else 0
+    with _on_device_of(grids):
+        _check(lib().p3d_mc_extract_fused_batched(
+            c_void_p(grids.data_ptr()), _dtype_code(grids), B, rx, ry, rz, c_float(thresh), byref(lo), byref(up),
+            c_void_p(ws.data_ptr()), c_void_p(vertices.data_ptr()) if capv else None, capv,
+            c_void_p(scratch.data_ptr()) if capv else None, scratch.shape[0] if capv else 0,
+            c_void_p(faces.data_ptr()) if capf else None, capf, c_void_p(item_offsets.data_ptr()),
+            _stream_ptr(grids)), "p3d_mc_extract_fused_batched")
 
 
 def debug_layout(rx, ry, rz):

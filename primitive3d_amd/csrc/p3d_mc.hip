@@ -48,16 +48,20 @@ __device__ const u64 g_tri_packed[256] = {P3D_TRI_TABLE_PACKED};
 __device__ const unsigned char g_tri_count[256] = {P3D_TRI_COUNT};
 
 struct Dims {
-    int64_t rx, ry, rz;
+    int64_t rx, ry, rz;   // rx = ALL planes of the call (a batch of B grids is a stack of B * xper planes)
     int64_t P;  // units per x plane = ry * ncz
     int64_t U;  // total units
     int ncz;    // 64-voxel chunks per z row
     int ztail;  // rz % 64
+    int64_t xper;   // planes per item: plane x belongs to item x / xper and has an upper neighbour unless it is the
+    int nitems;     // item's last plane (a single grid: xper = rx, nitems = 1)
+    int stack;      // 1: the batched entry (per-item cursor blocks in the workspace, item offsets written), even for B = 1
 };
 
 struct Ws {  // byte offsets into the workspace
-    size_t hdr, bits, rec, cnt, bsum_v, bbase_v, chunk_sum, wave_off, tile_tris, total;
-    int64_t nchunks;  // face chunks (tile column x face_chunk_planes planes)
+    size_t hdr, bits, rec, cnt, bsum_v, bbase_v, chunk_sum, wave_off, tile_tris, cur, total;
+    int64_t nchunks;  // face chunks (tile column x face_chunk_planes planes), all items
+    int64_t cpi;      // chunks per item
     int xw;
     int64_t nb_v, nb_f, tpp;  // unit blocks, face blocks, face tiles per plane
 };
@@ -78,14 +82,25 @@ __host__ __device__ inline Dims make_dims(int64_t rx, int64_t ry, int64_t rz) {
     d.ztail = (int)(rz % 64);
     d.P = ry * d.ncz;
     d.U = rx * d.P;
+    d.xper = rx;
+    d.nitems = 1;
+    d.stack = 0;
+    return d;
+}
+// B grids of [rx, ry, rz], back to back in memory
+__host__ __device__ inline Dims make_dims_stack(int64_t nitems, int64_t rx, int64_t ry, int64_t rz) {
+    Dims d = make_dims(nitems * rx, ry, rz);
+    d.xper = rx;
+    d.nitems = (int)nitems;
+    d.stack = 1;
     return d;
 }
 
 // face chunk = one tile column over this many planes: 8, doubled until there are at most 4096 chunks (every face tile
 // adds up the chunk totals before its own chunk: a few KiB of coalesced reads)
-inline int face_chunk_planes(int64_t rx, int64_t tpp) {
+inline int face_chunk_planes(int64_t rx, int64_t tpp, int64_t nitems = 1) {
     int xw = 8;
-    while (((rx - 1 + xw - 1) / xw) * tpp > 4096) xw *= 2;
+    while (((rx - 1 + xw - 1) / xw) * tpp * nitems > 4096) xw *= 2;
     return xw;
 }
 
@@ -111,14 +126,17 @@ Ws make_ws(const Dims& d) {
     o = align_up(o + scan_pad(w.nb_v) * 4, 256);
     w.bbase_v = o;
     o = align_up(o + scan_pad(w.nb_v) * 4, 256);
-    w.xw = face_chunk_planes(d.rx, w.tpp);
-    w.nchunks = d.rx > 1 ? ((d.rx - 1 + w.xw - 1) / w.xw) * w.tpp : 0;
+    w.xw = face_chunk_planes(d.xper, w.tpp, d.nitems);
+    w.cpi = d.xper > 1 ? ((d.xper - 1 + w.xw - 1) / w.xw) * w.tpp : 0;
+    w.nchunks = w.cpi * d.nitems;
     w.chunk_sum = o;   // triangles per chunk
     o = align_up(o + (size_t)(w.nchunks + 1) * 4, 256);
     w.wave_off = o;    // first face of every (tile, wave), relative to its chunk
     o = align_up(o + (size_t)(w.nb_f + 1) * 4 * 4, 256);
     w.tile_tris = o;   // triangles of every face tile (an empty tile's block returns at once)
     o = align_up(o + (size_t)(w.nb_f + 1) * 4, 256);
+    w.cur = o;         // a stack of items keeps one block of 32 vertex cursors per item here
+    if (d.stack) o = align_up(o + (size_t)d.nitems * 32 * 16 * 8, 256);
     w.total = o;
     return w;
 }
@@ -466,16 +484,35 @@ struct CompactArgs {
     int finish;            // block 0 also finishes the header and reports V and F
     const u32* chunk_sum;  // block 0 adds the chunk sums up to F
     int nchunks;
-    const u64* cursors;    // the call's cursor block
+    const u64* cursors;    // the call's cursor block (a stack of items: one block per item, back to back)
     u32 id_limit;          // vertices a region may number (2^26: ids are region * 2^26 + slot); beyond it ids alias
+    int nitems;            // items of a stack (0 / 1: a single grid)
+    int64_t* item_offsets; // stack only: [nitems + 1] vertex offsets, [nitems + 1] face offsets (device memory)
 };
 typedef float F4U __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access at 4-byte alignment
 typedef float F4A __attribute__((ext_vector_type(4)));
+// A stack of items (a batch of grids) has one cursor block and 32 scratch regions per item: the launch's compaction
+// blocks are split evenly over the items (c.nblocks = nitems * slices * 32), an item's vertices land behind those of the
+// items before it, and the finishing block also writes the per-item vertex and face offsets (c.item_offsets:
+// [nitems + 1] vertex offsets, then [nitems + 1] face offsets, int64).
 __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr, u64* mb, u64 seq) {
     __shared__ u64 s_cur[kRegions], s_pre[kRegions];
+    __shared__ u64 s_item_base, s_red[4];
     const int tid = threadIdx.x, lane = tid & 63;
+    const int nitems = c.nitems > 0 ? c.nitems : 1;
+    const int per_item = c.nblocks / nitems;                       // compaction blocks per item (multiple of 32)
+    const int item = per_item > 0 ? (int)blockIdx.x / per_item : 0;
+    const int jb = per_item > 0 ? (int)blockIdx.x - item * per_item : 0;
+    const u64* const cursors = c.cursors + (size_t)item * kCursorBlockWords;
+    const bool finisher = blockIdx.x == 0 && c.finish;
     if (tid < 64) {
-        const u64 cur = lane < kRegions ? c.cursors[lane * kCursorStride] : 0ull;
+        // vertices of the items before this one (a single grid: nothing to add)
+        u64 before = 0;
+        for (int i = lane; i < item * kRegions; i += 64) before += c.cursors[(size_t)i * kCursorStride];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) before += __shfl_down(before, o, 64);
+        before = readlane64(before, 0);
+        const u64 cur = lane < kRegions ? cursors[lane * kCursorStride] : 0ull;
         u64 inc = cur;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -486,7 +523,8 @@ __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr
             s_cur[lane] = cur;
             s_pre[lane] = inc - cur;
         }
-        if (blockIdx.x == 0 && c.finish) {
+        if (lane == 0) s_item_base = before;
+        if (finisher && !c.item_offsets) {
             const u64 over = __ballot(cur > (u64)(c.scratch ? c.store_rows : c.region_rows));
             const u64 wrap = __ballot(cur > (u64)c.id_limit);   // a region outgrew its id space: ids are ambiguous
             const u64 flags = (over ? 1ull : 0ull) | (wrap ? 2ull : 0ull);
@@ -500,8 +538,52 @@ __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr
         }
     }
     __syncthreads();
-    if (blockIdx.x == 0 && c.finish) {
-        __shared__ u64 s_red[4];
+    if (finisher && c.item_offsets) {
+        // totals, flags and the per-item offsets of a stack: thread t takes items t, t + 256, ...
+        __shared__ u64 s_nv[kBlock], s_nf[kBlock];
+        __shared__ u32 s_flag;
+        if (tid == 0) s_flag = 0;
+        __syncthreads();
+        const int cpi = c.nchunks / nitems;
+        u64 run_v = 0, run_f = 0;
+        for (int i0 = 0; i0 < nitems; i0 += kBlock) {
+            const int i = i0 + tid;
+            u64 nv = 0, nf = 0;
+            u32 fl = 0;
+            if (i < nitems) {
+                for (int r = 0; r < kRegions; ++r) {
+                    const u64 cur = c.cursors[((size_t)i * kRegions + r) * kCursorStride];
+                    nv += cur;
+                    if (cur > (u64)(c.scratch ? c.store_rows : c.region_rows)) fl |= 1u;
+                    if (cur > (u64)c.id_limit) fl |= 2u;
+                }
+                for (int k = 0; k < cpi; ++k) nf += c.chunk_sum[(size_t)i * cpi + k];
+            }
+            if (fl) atomicOr(&s_flag, fl);
+            s_nv[tid] = nv;
+            s_nf[tid] = nf;
+            __syncthreads();
+            if (tid == 0) {  // (a few hundred items at most: a serial pass over the block's share)
+                for (int k = 0; k < kBlock && i0 + k < nitems; ++k) {
+                    c.item_offsets[i0 + k] = (int64_t)run_v;
+                    c.item_offsets[nitems + 1 + i0 + k] = (int64_t)run_f;
+                    run_v += s_nv[k];
+                    run_f += s_nf[k];
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            c.item_offsets[nitems] = (int64_t)run_v;
+            c.item_offsets[2 * nitems + 1] = (int64_t)run_f;
+            hdr[H_V] = run_v;
+            hdr[H_T] = run_f;
+            hdr[H_FLAGS] = s_flag;
+            hdr[H_RECFORM] = 1ull;
+            mb_publish_v(mb, seq, run_v, s_flag);
+            mb_publish_f(mb, seq, run_f);
+        }
+    } else if (finisher) {
         u64 part_sum = 0;
         for (int i = tid; i < c.nchunks; i += kBlock) part_sum += c.chunk_sum[i];
 #pragma unroll
@@ -515,12 +597,12 @@ __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr
         }
     }
     if (!c.scratch || c.capv <= 0) return;
-    const int r = blockIdx.x % kRegions, part = c.part0 + blockIdx.x / kRegions, nparts = c.nparts;
+    const int r = jb % kRegions, part = c.part0 + jb / kRegions, nparts = c.nparts;
     const int64_t rows = (int64_t)min(s_cur[r], (u64)c.store_rows);
-    const int64_t dst0 = (int64_t)s_pre[r] * 3;
+    const int64_t dst0 = (int64_t)(s_item_base + s_pre[r]) * 3;
     const int64_t n = min(rows * 3, c.capv * 3 - dst0);  // floats to move (<= 0: nothing fits)
     if (n <= 0) return;
-    const float* __restrict__ src = c.scratch + (size_t)r * c.store_rows * 3;
+    const float* __restrict__ src = c.scratch + ((size_t)item * kRegions + r) * c.store_rows * 3;
     float* __restrict__ dst = c.verts + dst0;
     const int64_t head = min(n, (int64_t)((4 - (dst0 & 3)) & 3));  // floats before the first 16-byte boundary of dst
     const int64_t nvec = (n - head) >> 2;
@@ -570,8 +652,12 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
     __shared__ u32 s_part[PB][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t chunk = (int64_t)blockIdx.x - cp.nblocks;
-    const int64_t xc = chunk / tpp, tile = chunk - xc * tpp;
-    const int64_t x_begin = xc * xw, x_end = min(x_begin + xw, d.rx - 1);  // cell layers [x_begin, x_end)
+    // chunks are numbered item by item (a single grid is one item): cpi chunks each, none straddles two items
+    const int64_t cpi = d.xper > 1 ? ((d.xper - 1 + xw - 1) / xw) * tpp : 1;
+    const int64_t item = chunk / cpi, cl = chunk - item * cpi;
+    const int64_t xc = cl / tpp, tile = cl - xc * tpp;
+    const int64_t x_begin = item * d.xper + xc * xw;
+    const int64_t x_end = min(x_begin + xw, item * d.xper + d.xper - 1);  // cell layers [x_begin, x_end)
     const int64_t p = tile * kBlock + tid;
     const int64_t y = p / d.ncz;
     const int c = (int)(p - y * d.ncz);
@@ -759,7 +845,9 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     s_ntri[tid] = g_tri_count[tid];
     if (XLATE && wave == 0) {  // dense base of every region = exclusive prefix over the region cursors
         if (a.xlate == 1) {
-            const u32 cnt = lane < kRegions ? (u32)a.cursors[lane * kCursorStride] : 0u;
+            // (a stack of items: the cursor block of this tile's item; vertex ids are local to the item)
+            const int64_t it = (((int64_t)blockIdx.x - cp.nblocks) / a.tpp) / d.xper;
+            const u32 cnt = lane < kRegions ? (u32)a.cursors[(size_t)it * kCursorBlockWords + lane * kCursorStride] : 0u;
             const u32 inc = wave_prefix_sum(cnt);
             if (lane < kRegions) s_pref[lane] = inc - cnt;
         } else if (lane < kRegions) {
@@ -769,9 +857,11 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     auto dense = [&](u32 v) -> u32 { return XLATE ? (v & 0x3ffffffu) + s_pref[(v >> 26) & (kRegions - 1)] : v; };
 
     const int64_t b = (int64_t)blockIdx.x - cp.nblocks;
-    const u32 my_tris = a.tile_tris[b];   // (the loads below are issued before this value is looked at)
     const int64_t x = b / a.tpp;
     const int64_t tile = b - x * a.tpp;
+    const int64_t item = x / d.xper, xl = x - item * d.xper;
+    if (xl == d.xper - 1) return;   // the last plane of an item has no cell layer above it (stack of items only)
+    const u32 my_tris = a.tile_tris[b];   // (the loads below are issued before this value is looked at)
     const int64_t p = tile * kBlock + tid;
     const int64_t y = p / d.ncz;
     const int c = (int)(p - y * d.ncz);
@@ -809,7 +899,8 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     // faces of the chunks before this tile's chunk (summed by the whole block)
     u32 cs = 0;
     {
-        const int64_t mychunk = (x / a.xw) * a.tpp + tile;
+        const int64_t cpi = d.xper > 1 ? ((d.xper - 1 + a.xw - 1) / a.xw) * a.tpp : 1;
+        const int64_t mychunk = item * cpi + (xl / a.xw) * a.tpp + tile;
         for (int64_t i = tid; i < mychunk; i += kBlock) cs += a.chunk_sum[i];
     }
     if (my_tris == 0u) return;  // nothing to emit here (block-uniform; most tiles of a sparse field)
@@ -1224,7 +1315,7 @@ int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3
     }
     if (w.nchunks > 0) {
         StageTimer tm(ST_FACES_COUNT, st);
-        const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr, 1u << 26};
+        const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr, 1u << 26, 1, nullptr};
         hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)w.nchunks), dim3(kBlock), 0, st, bits, d, w.tpp, w.xw, csum,
                            woff, (u32*)(ws + w.tile_tris), none, hdr);
     }
@@ -1262,7 +1353,7 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
                          slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw,
                          (const u32*)(ws + w.chunk_sum), (const u32*)(ws + w.wave_off),
                          (const u32*)(ws + w.tile_tris), nullptr, nullptr, 0};
-        const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr, 1u << 26};
+        const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr, 1u << 26, 1, nullptr};
         launch_faces(d, w, bits, rec, a, none, hdr, faces, capf, true, st);
     }
     HIP_TRY(hipGetLastError());
@@ -1278,13 +1369,15 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
     FusedGeom g;
     g.x_lo = x_lo;
     g.x_hi = x_hi;
-    const int64_t nplanes = x_hi - x_lo;
+    g.nxt_item = 0;
+    const bool stack = d.stack != 0;   // a batch of grids: every x-slab lies inside one item, all items in one launch
+    const int64_t nplanes = stack ? d.xper : x_hi - x_lo;
     if (nplanes <= 0) return;
     g.nzt = (d.ncz + NC - 1) / NC;
     g.nyt = (int)((d.ry + kFusedWPB * RY - 1) / (kFusedWPB * RY));
     // planes per block: enough blocks to fill the chip a few times over, but >= 8 planes (x-halo overhead 1/XT)
     // unless the grid is so small that 8-plane blocks would leave most CUs idle (then latency wins over the halo)
-    const int64_t per_slab = (int64_t)g.nzt * g.nyt;
+    const int64_t per_slab = (int64_t)g.nzt * g.nyt * (stack ? d.nitems : 1);
     int64_t want_slabs = (env_int("P3D_FUSED_BLOCKS", 4096) + per_slab - 1) / per_slab;
     int xt = (int)((nplanes + want_slabs - 1) / want_slabs);
     if (xt < 8) {
@@ -1308,6 +1401,12 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
     g.XT_tail = xt_tail > 0 ? xt_tail : 1;
     const int64_t rest = nplanes - n_big * xt;
     g.nxt = (int)(n_big + (rest > 0 ? (rest + g.XT_tail - 1) / g.XT_tail : 0));
+    if (stack) {   // uniform slabs, no taper (many items: the tail of the launch is short anyway)
+        g.nxt_item = (int)((nplanes + xt - 1) / xt);
+        g.nxt = g.nxt_item;   // (per_slab already counts the items)
+        g.n_big = g.nxt;
+        g.XT_tail = xt;
+    }
     const int64_t nblocks = per_slab * g.nxt;
     // (the timing events, if any, ride on the dispatch packet itself: no extra barrier packets around the kernel)
     if (ev0)
@@ -1323,8 +1422,18 @@ void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const 
                     uint2* rec, u64* cursors, u64* zero_next, float* scratch, u32 region_rows, u32 store_rows, int x_lo,
                   int x_hi,
                     hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
-    // two tile geometries (both hold 32 unit words per wave-plane): long rows / short rows
-    if (d.ncz >= 3)
+    // three tile geometries (all hold 32 unit words per wave-plane): long rows (8 chunks x 3 rows per wave), rows of
+    // 3-4 chunks (rz <= 256: 4 chunks x 7 rows -- the 8-chunk tile would be half empty), short rows (2 chunks x 15 rows)
+    if (d.ncz >= 5)
+        launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                              store_rows, x_lo, x_hi, ev0, ev1, st);
+    else if (d.ncz >= 3 &&
+             // (only when 8-plane slabs of the wider-in-y tile still give the chip enough blocks: a single small grid is
+             //  better off with more, half-empty tiles than with 2-plane slabs)
+             ((d.ry + 27) / 28) * (d.stack ? d.nitems : 1) * ((x_hi - x_lo + 7) / 8) >= 1024)
+        launch_fused<T, 4, 7>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                              store_rows, x_lo, x_hi, ev0, ev1, st);
+    else if (d.ncz >= 3)
         launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
                               store_rows, x_lo, x_hi, ev0, ev1, st);
     else
@@ -1411,7 +1520,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     if (w.nchunks > 0 && part != 5) {
         StageTimer tm(ST_FACES_COUNT, st);
         const CompactArgs cpe{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, early * kRegions, 0, nparts, 0,
-                              csum, (int)w.nchunks, cursors, id_limit};
+                              csum, (int)w.nchunks, cursors, id_limit, 1, nullptr};
         hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)(w.nchunks + cpe.nblocks)), dim3(kBlock), 0, st, bits,
                            d, w.tpp, w.xw, csum, woff, (u32*)(ws + w.tile_tris), cpe, hdr);
     }
@@ -1425,9 +1534,52 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
                      slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw,
                      csum, woff, (const u32*)(ws + w.tile_tris), cursors, mb, seq};
     const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, (nparts - early) * kRegions, early,
-                         nparts, part == 5 ? 0 : 1, csum, (int)w.nchunks, cursors, id_limit};
+                         nparts, part == 5 ? 0 : 1, csum, (int)w.nchunks, cursors, id_limit, 1, nullptr};
     StageTimer tm(ST_EMIT_FACES, st);
     launch_faces(d, w, bits, rec, a, cp, hdr, faces, capf, faces_here, st);
+    HIP_TRY(hipGetLastError());
+    return P3D_OK;
+}
+
+// A batch of B grids of one shape, back to back in memory, as ONE stack of B * rx planes: one streaming launch, one
+// counting launch, one face launch for the whole batch (a 256^3 grid alone cannot fill the chip: launch ramp and tail
+// dominate its three kernels).  Every item fills its own 32 vertex regions, so its vertices are contiguous in the
+// output and its face indices are local to it; the item offsets are written to device memory by the face launch.
+template <typename T>
+int fused_stack_impl(const T* grids, const Dims& d, const Ws& w, float thresh, const Xform& t, char* ws, float* verts,
+                     int64_t capv, float* scratch, int64_t scratch_rows, int32_t* faces, int64_t capf,
+                     int64_t* item_offsets, hipStream_t st) {
+    u64* hdr = (u64*)(ws + w.hdr);
+    u64* bits = (u64*)(ws + w.bits);
+    uint2* rec = (uint2*)(ws + w.rec);
+    u32 *csum = (u32*)(ws + w.chunk_sum), *woff = (u32*)(ws + w.wave_off);
+    u64* cursors = (u64*)(ws + w.cur);
+    HIP_TRY(hipMemsetAsync(cursors, 0, (size_t)d.nitems * kCursorBlockWords * sizeof(u64), st));
+    const u32 region_rows = 1u << 26;
+    const u32 id_limit = (u32)std::min<int64_t>(region_rows, std::max(1, env_int("P3D_TEST_ID_LIMIT", 1 << 26)));
+    const u32 store_rows =
+        scratch ? (u32)std::min<int64_t>(scratch_rows / ((int64_t)kRegions * d.nitems), (int64_t)region_rows) : 0u;
+    const bool timed = g_prof_mode != 0;
+    if (timed) g_ev_used[ST_FUSED] = true;
+    g_ev_used[ST_FUSED_INTERIOR] = false;
+    dispatch_fused<T>(grids, d, thresh, 0, t, 0, bits, rec, cursors, nullptr, scratch, region_rows, store_rows, 0, (int)d.rx,
+                      timed ? g_ev[ST_FUSED][0] : nullptr, timed ? g_ev[ST_FUSED][1] : nullptr, st);
+    u64 seq = 0;
+    u64* mb = mailbox_open(ws, &seq);
+    const bool copy = scratch && capv > 0;
+    // compaction blocks: about a thousand for the whole stack, at least one per (item, region)
+    const int nparts = copy ? std::max(1, std::min(8, 1024 / (kRegions * d.nitems))) : 1;
+    const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr, 1u << 26, 1, nullptr};
+    if (w.nchunks > 0) {
+        StageTimer tm(ST_FACES_COUNT, st);
+        hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)w.nchunks), dim3(kBlock), 0, st, bits, d, w.tpp,
+                           w.xw, csum, woff, (u32*)(ws + w.tile_tris), none, hdr);
+    }
+    const FaceArgs a{1, 0, 0, 0, nullptr, 0, w.tpp, w.xw, csum, woff, (const u32*)(ws + w.tile_tris), cursors, mb, seq};
+    const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, nparts * kRegions * d.nitems, 0,
+                         nparts, 1, csum, (int)w.nchunks, cursors, id_limit, d.nitems, item_offsets};
+    StageTimer tm(ST_EMIT_FACES, st);
+    launch_faces(d, w, bits, rec, a, cp, hdr, faces, capf, w.nb_f > 0 && capf > 0, st);
     HIP_TRY(hipGetLastError());
     return P3D_OK;
 }
@@ -1523,6 +1675,40 @@ int p3d_mc_extract_fused(const void* grid, int dtype, int64_t rx, int64_t ry, in
     if (dtype == P3D_F16)
         return fused_impl((const __half*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices,
                           vertex_scratch, scratch_rows, faces, cap_faces, st);
+    return fail(P3D_EINVAL, "unknown dtype%s");
+}
+
+int p3d_mc_workspace_bytes_batched(int64_t nitems, int64_t rx, int64_t ry, int64_t rz, size_t* bytes) {
+    if (!bytes) return fail(P3D_EINVAL, "bytes is null%s");
+    if (nitems < 1 || nitems > 65535) return fail(P3D_EINVAL, "nitems must be in [1, 65535]%s");
+    if (int rc = check_dims(nitems * rx, ry, rz)) return rc;
+    *bytes = make_ws(make_dims_stack(nitems, rx, ry, rz)).total;
+    return P3D_OK;
+}
+
+int p3d_mc_extract_fused_batched(const void* grids, int dtype, int64_t nitems, int64_t rx, int64_t ry, int64_t rz,
+                                 float thresh, const float lower[3], const float upper[3], void* ws, float* vertices,
+                                 int64_t cap_vertices, float* vertex_scratch, int64_t scratch_rows, int32_t* faces,
+                                 int64_t cap_faces, int64_t* item_offsets, void* stream) {
+    if (!grids || !ws || !lower || !upper || !item_offsets) return fail(P3D_EINVAL, "null pointer%s");
+    if ((cap_vertices > 0 && !vertices) || (cap_faces > 0 && !faces)) return fail(P3D_EINVAL, "null output%s");
+    if (cap_vertices < 0 || cap_faces < 0 || scratch_rows < 0) return fail(P3D_EINVAL, "negative capacity%s");
+    if (nitems < 1 || nitems > 65535) return fail(P3D_EINVAL, "nitems must be in [1, 65535]%s");
+    if (rx < 1) return fail(P3D_EINVAL, "grid dims must be >= 1%s");
+    if (cap_vertices > 0 && (!vertex_scratch || scratch_rows < kRegions * nitems))
+        return fail(P3D_EINVAL, "vertex output needs a scratch buffer of at least 32 rows per item%s");
+    if (int rc = check_dims(nitems * rx, ry, rz)) return rc;
+    const Dims d = make_dims_stack(nitems, rx, ry, rz);
+    const Ws w = make_ws(d);
+    const Dims d1 = make_dims(rx, ry, rz);   // the box transform is the single grid's (marching_cubes.cu:293-297)
+    const Xform t = make_xform(d1, lower, upper, nullptr);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == P3D_F32)
+        return fused_stack_impl((const float*)grids, d, w, thresh, t, (char*)ws, vertices, cap_vertices, vertex_scratch,
+                                scratch_rows, faces, cap_faces, item_offsets, st);
+    if (dtype == P3D_F16)
+        return fused_stack_impl((const __half*)grids, d, w, thresh, t, (char*)ws, vertices, cap_vertices,
+                                vertex_scratch, scratch_rows, faces, cap_faces, item_offsets, st);
     return fail(P3D_EINVAL, "unknown dtype%s");
 }
 

@@ -110,8 +110,10 @@ def marching_cubes_batched(density_grids, thresh: float, scale=None):
     up-casts to fp32, marching_cubes.py:87): `density_grids` is a [B, rx, ry, rz] CUDA tensor of
     float32 **or float16**; fp16 grids are read as fp16 (half the HBM bytes) and compared in fp32,
     which is exactly the reference applied to `density_grids[b].float()` (the conversion is exact).
+    The whole batch is ONE call of the native library (include/p3d_mc.h: p3d_mc_extract_fused_batched: one
+    streaming launch, one counting launch and one face launch for all items).
     Returns (vertices [sumV,3] f32, faces [sumF,3] i32 with per-item LOCAL vertex ids,
-    vertex_offsets [B+1] i64, face_offsets [B+1] i64).
+    vertex_offsets [B+1] i64, face_offsets [B+1] i64 -- all four on the device).
     """
     from . import capi
     if isinstance(density_grids, np.ndarray):
@@ -121,37 +123,57 @@ def marching_cubes_batched(density_grids, thresh: float, scale=None):
         density_grids = density_grids.to(torch.float32)
     if density_grids.dim() != 4 or min(density_grids.shape[1:]) < 2:
         raise ValueError()
-    shape = density_grids.shape[1:]
+    density_grids = density_grids.contiguous()
+    B = density_grids.shape[0]
+    shape = tuple(density_grids.shape[1:])
     if scale is None:
         lower, upper = [0.0, 0.0, 0.0], [shape[0], shape[1], shape[2]]
     else:
         lower, upper = scale_to_bound(scale)
-    # software pipeline over the items: item b+1 is launched BEFORE the host reads the totals of item b (the
-    # totals come through the library's pinned mailbox), so the GPU never waits for the host between items
-    nvox = shape[0] * shape[1] * shape[2]
+    dev = density_grids.device
+    if B == 0:
+        z = torch.zeros(1, dtype=torch.int64, device=dev)
+        return (torch.empty((0, 3), dtype=torch.float32, device=dev), torch.empty((0, 3), dtype=torch.int32, device=dev),
+                z, z.clone())
+    nvox = B * shape[0] * shape[1] * shape[2]
+    ws = torch.empty(capi.workspace_bytes_batched(B, *shape), dtype=torch.uint8, device=dev)
+    offs = torch.empty(2 * (B + 1), dtype=torch.int64, device=dev)
+    key = (dev.index, B) + shape
+    capv, capf, slack = _BATCH_HINTS.get(key, (max(4096, nvox // 16), 2 * max(4096, nvox // 16), 5))
+    for attempt in range(3):
+        per_region = (capv + 32 * B - 1) // (32 * B)
+        rows = 32 * B * max(per_region * slack // 4 + 256, min(capv, 2048))
+        v = torch.empty((capv, 3), dtype=torch.float32, device=dev)
+        f = torch.empty((capf, 3), dtype=torch.int32, device=dev)
+        scratch = torch.empty((rows, 3), dtype=torch.float32, device=dev)
+        capi.extract_fused_batched_raw(density_grids, thresh, lower, upper, ws, v, scratch, f, offs)
+        nv, nf, flags = capi.read_counts(ws, with_flags=True)
+        fitted = nv <= capv and nf <= capf and not flags
+        if len(_BATCH_HINTS) >= 256 and key not in _BATCH_HINTS:
+            _BATCH_HINTS.clear()
+        _BATCH_HINTS[key] = (nv + nv // 8 + 4096, nf + nf // 8 + 4096, min(32, 2 * slack) if flags & 1 else slack)
+        if fitted:  # (the offsets stay on the device like the meshes: no synchronisation inside the call)
+            return v[:nv], f[:nf], offs[:B + 1], offs[B + 1:]
+        if flags & 2:
+            break  # an item numbered more than 2^26 vertices in one region: only the per-item path can renumber
+        capv, capf, slack = nv, nf, min(32, max(8, 2 * slack))   # exact sizes are known now: stream once more
+    return _batched_item_by_item(density_grids, thresh, lower, upper)
+
+
+_BATCH_HINTS = {}   # (device, B, rx, ry, rz) -> (vertex capacity, face capacity, scratch slack in quarters)
+
+
+def _batched_item_by_item(density_grids, thresh, lower, upper):
+    """Last resort of marching_cubes_batched (pathological region imbalance, id-space overflow): one single-grid call of
+    the C ABI per item, exact re-emission when a guess was too small."""
+    from . import capi
     B = density_grids.shape[0]
-    vs, fs, pending = [], [], None
-    capv, capf = max(1024, nvox // 16), 2 * max(1024, nvox // 16)  # first guess; then the previous item's sizes
-    for b in range(B + 1):
-        cur = None
-        if b < B:
-            g = density_grids[b].contiguous()
-            ws = torch.empty(capi.workspace_bytes(*shape), dtype=torch.uint8, device=g.device)
-            v = torch.empty((capv, 3), dtype=torch.float32, device=g.device)
-            f = torch.empty((capf, 3), dtype=torch.int32, device=g.device)
-            capi.extract_fused_raw(g, thresh, lower, upper, ws, v, f)
-            cur = (g, ws, v, f)
-        if pending is not None:
-            g0, ws0, v0, f0 = pending
-            nv, nf, over = capi.read_counts(ws0, with_flags=True)
-            if nv > v0.shape[0] or nf > f0.shape[0] or over:  # guess too small: exact re-emission (ids stay valid)
-                v0 = torch.empty((nv, 3), dtype=torch.float32, device=g0.device)
-                f0 = torch.empty((nf, 3), dtype=torch.int32, device=g0.device)
-                capi.emit(g0, thresh, lower, upper, ws0, v0, f0)
-            vs.append(v0[:nv])
-            fs.append(f0[:nf])
-            capv, capf = nv + nv // 8 + 4096, nf + nf // 8 + 4096
-        pending = cur
-    voff = torch.tensor([0] + [v.shape[0] for v in vs], dtype=torch.int64).cumsum(0)
-    foff = torch.tensor([0] + [f.shape[0] for f in fs], dtype=torch.int64).cumsum(0)
+    vs, fs = [], []
+    for b in range(B):
+        v, f = capi.extract_fused(density_grids[b], thresh, lower, upper)
+        vs.append(v)
+        fs.append(f)
+    dev = density_grids.device
+    voff = torch.tensor([0] + [v.shape[0] for v in vs], dtype=torch.int64).cumsum(0).to(dev)
+    foff = torch.tensor([0] + [f.shape[0] for f in fs], dtype=torch.int64).cumsum(0).to(dev)
     return torch.cat(vs), torch.cat(fs), voff, foff

@@ -108,6 +108,42 @@ def test_c5_batched_fp16(gpu, built):
     mesh_properties(v, f)
 
 
+@pytest.mark.parametrize("shape,B,dtype", [((7, 9, 70), 5, torch.float32), ((33, 17, 200), 3, torch.float16),
+                                           ((2, 2, 2), 9, torch.float32), ((12, 40, 517), 2, torch.float32),
+                                           ((24, 24, 24), 1, torch.float16)])
+def test_batched_call_equals_per_item_oracle(gpu, built, shape, B, dtype):
+    """The one-launch batched entry on odd shapes (ragged rz, tiny items, a single item): every item's mesh == the
+    oracle's mesh of that item alone (triangle soup, bit for bit), face ids local to the item."""
+    from oracle import oracle_extract
+    rng = np.random.default_rng(sum(shape) + B)
+    grids = torch.from_numpy(rng.standard_normal((B,) + shape).astype(np.float32)).to(dtype)
+    lower, upper = [0.5, -1.0, 2.0], [3.0, 4.0, 9.0]
+    v, f, vo, fo = built.marching_cubes_batched(grids.to(gpu), 0.1, scale=(lower, upper))
+    torch.cuda.synchronize()
+    assert int(vo[0]) == 0 and int(fo[0]) == 0 and int(vo[-1]) == v.shape[0] and int(fo[-1]) == f.shape[0]
+    soup = lambda vv, ff: np.sort(vv[ff.astype(np.int64)].reshape(len(ff), 9).view([("", np.float32)] * 9), axis=0)
+    for b in range(B):
+        rv, rf, _ = oracle_extract(grids[b].float().numpy(), 0.1, lower, upper)
+        vb, fb = v[vo[b]:vo[b + 1]].cpu().numpy(), f[fo[b]:fo[b + 1]].cpu().numpy()
+        assert vb.shape == rv.shape and fb.shape == rf.shape, (b, vb.shape, rv.shape, fb.shape, rf.shape)
+        assert fb.size == 0 or (fb.min() >= 0 and fb.max() < vb.shape[0])
+        assert np.array_equal(soup(vb, fb), soup(rv, rf)), b
+    # a second call takes the size hints of the first
+    v2, f2, vo2, fo2 = built.marching_cubes_batched(grids.to(gpu), 0.1, scale=(lower, upper))
+    assert torch.equal(vo2, vo) and torch.equal(fo2, fo)
+
+
+def test_batched_call_falls_back_item_by_item(gpu, built, monkeypatch):
+    """P3D_TEST_ID_LIMIT makes every region report an id-space overflow: the wrapper must return the same meshes
+    through its per-item path."""
+    from oracle import oracle_count
+    grids = torch.from_numpy(np.random.default_rng(3).standard_normal((3, 10, 11, 70)).astype(np.float32))
+    monkeypatch.setenv("P3D_TEST_ID_LIMIT", "4")
+    v, f, vo, fo = built.marching_cubes_batched(grids.to(gpu), 0.0)
+    for b in range(3):
+        assert (int(vo[b + 1] - vo[b]), int(fo[b + 1] - fo[b])) == oracle_count(grids[b].numpy(), 0.0)
+
+
 def test_c5_32x256_fp16_full_batch(gpu, built):
     """BASELINE.json configs[4] at its stated size: 32 x 256^3 fp16 density grids through marching_cubes_batched.
     Every item: counts against the independent torch count + mesh properties; four items: the whole mesh (triangle

@@ -12,3 +12,7 @@ for _ in range(5): out = p3d.marching_cubes_batched(grids, 0.0)
 torch.cuda.synchronize(); t1 = time.perf_counter()
 dt = (t1 - t0) / 5
 print("batch of %d x 256^3 fp16: %.2f ms  (%.1f us/item, %.0f Mvoxels/s)  V=%d F=%d" % (B, dt * 1e3, dt / B * 1e6, B * 256**3 / dt / 1e6, out[0].shape[0], out[1].shape[0]))
+from primitive3d_amd import capi
+capi.profile_enable(2)
+out = p3d.marching_cubes_batched(grids, 0.0); torch.cuda.synchronize()
+print({k: round(t * 1e3, 1) for k, t in capi.profile_read().items()}, "us")
