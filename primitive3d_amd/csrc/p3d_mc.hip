@@ -450,7 +450,10 @@ struct FaceArgs {
     int rank;
     int64_t tpp;           // tiles per plane
     int xw;                // planes per chunk (face_chunk_planes)
+    int cpi;               // chunks per item (a single grid: all chunks)
     const u32* chunk_sum;  // [nchunks] triangles per chunk
+    const u32* chunk_pre;  // optional [nchunks] exclusive prefix of chunk_sum (a stack of items has up to 4096 chunks:
+                           // one small scan launch instead of a 16 KiB read per face tile); null: tiles add them up
     const u32* wave_off;   // [nb_f * 4] first face of (tile, wave) relative to its chunk
     const u32* tile_tris;  // [nb_f] triangles of the tile
     const u64* cursors;    // xlate: the call's 32 vertex-region cursors
@@ -487,14 +490,13 @@ struct CompactArgs {
     const u64* cursors;    // the call's cursor block (a stack of items: one block per item, back to back)
     u32 id_limit;          // vertices a region may number (2^26: ids are region * 2^26 + slot); beyond it ids alias
     int nitems;            // items of a stack (0 / 1: a single grid)
-    int64_t* item_offsets; // stack only: [nitems + 1] vertex offsets, [nitems + 1] face offsets (device memory)
+    int64_t* item_offsets; // (unused by the riding blocks; kept so that both call flavours build one argument struct)
 };
 typedef float F4U __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access at 4-byte alignment
 typedef float F4A __attribute__((ext_vector_type(4)));
 // A stack of items (a batch of grids) has one cursor block and 32 scratch regions per item: the launch's compaction
-// blocks are split evenly over the items (c.nblocks = nitems * slices * 32), an item's vertices land behind those of the
-// items before it, and the finishing block also writes the per-item vertex and face offsets (c.item_offsets:
-// [nitems + 1] vertex offsets, then [nitems + 1] face offsets, int64).
+// blocks are split evenly over the items (c.nblocks = nitems * slices * 32) and an item's vertices land behind those of
+// the items before it; the totals and per-item offsets of a stack are written by k_stack_finish, not here.
 __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr, u64* mb, u64 seq) {
     __shared__ u64 s_cur[kRegions], s_pre[kRegions];
     __shared__ u64 s_item_base, s_red[4];
@@ -524,7 +526,7 @@ __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr
             s_pre[lane] = inc - cur;
         }
         if (lane == 0) s_item_base = before;
-        if (finisher && !c.item_offsets) {
+        if (finisher) {
             const u64 over = __ballot(cur > (u64)(c.scratch ? c.store_rows : c.region_rows));
             const u64 wrap = __ballot(cur > (u64)c.id_limit);   // a region outgrew its id space: ids are ambiguous
             const u64 flags = (over ? 1ull : 0ull) | (wrap ? 2ull : 0ull);
@@ -538,52 +540,7 @@ __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr
         }
     }
     __syncthreads();
-    if (finisher && c.item_offsets) {
-        // totals, flags and the per-item offsets of a stack: thread t takes items t, t + 256, ...
-        __shared__ u64 s_nv[kBlock], s_nf[kBlock];
-        __shared__ u32 s_flag;
-        if (tid == 0) s_flag = 0;
-        __syncthreads();
-        const int cpi = c.nchunks / nitems;
-        u64 run_v = 0, run_f = 0;
-        for (int i0 = 0; i0 < nitems; i0 += kBlock) {
-            const int i = i0 + tid;
-            u64 nv = 0, nf = 0;
-            u32 fl = 0;
-            if (i < nitems) {
-                for (int r = 0; r < kRegions; ++r) {
-                    const u64 cur = c.cursors[((size_t)i * kRegions + r) * kCursorStride];
-                    nv += cur;
-                    if (cur > (u64)(c.scratch ? c.store_rows : c.region_rows)) fl |= 1u;
-                    if (cur > (u64)c.id_limit) fl |= 2u;
-                }
-                for (int k = 0; k < cpi; ++k) nf += c.chunk_sum[(size_t)i * cpi + k];
-            }
-            if (fl) atomicOr(&s_flag, fl);
-            s_nv[tid] = nv;
-            s_nf[tid] = nf;
-            __syncthreads();
-            if (tid == 0) {  // (a few hundred items at most: a serial pass over the block's share)
-                for (int k = 0; k < kBlock && i0 + k < nitems; ++k) {
-                    c.item_offsets[i0 + k] = (int64_t)run_v;
-                    c.item_offsets[nitems + 1 + i0 + k] = (int64_t)run_f;
-                    run_v += s_nv[k];
-                    run_f += s_nf[k];
-                }
-            }
-            __syncthreads();
-        }
-        if (tid == 0) {
-            c.item_offsets[nitems] = (int64_t)run_v;
-            c.item_offsets[2 * nitems + 1] = (int64_t)run_f;
-            hdr[H_V] = run_v;
-            hdr[H_T] = run_f;
-            hdr[H_FLAGS] = s_flag;
-            hdr[H_RECFORM] = 1ull;
-            mb_publish_v(mb, seq, run_v, s_flag);
-            mb_publish_f(mb, seq, run_f);
-        }
-    } else if (finisher) {
+    if (finisher) {
         u64 part_sum = 0;
         for (int i = tid; i < c.nchunks; i += kBlock) part_sum += c.chunk_sum[i];
 #pragma unroll
@@ -629,6 +586,56 @@ __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr
     for (; i < nvec; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(s4 + i), d4 + i);
 }
 
+// Totals, flags and per-item offsets of a stack of items (one wave; launched after the face kernel of a batched call).
+// item_offsets: [nitems + 1] vertex offsets, then [nitems + 1] face offsets.
+__global__ void k_stack_finish(const u64* __restrict__ cursors, const u32* __restrict__ chunk_sum, int nchunks, int nitems,
+                               u32 rows_limit, u32 id_limit, int64_t* __restrict__ item_offsets, u64* __restrict__ hdr,
+                               u64* mb, u64 seq) {
+    const int lane = threadIdx.x;
+    const int cpi = nchunks / nitems;
+    u64 run_v = 0, run_f = 0;
+    u32 flags = 0;
+    for (int i0 = 0; i0 < nitems; i0 += 64) {   // lane l takes items l, l + 64, ...
+        const int i = i0 + lane;
+        u64 nv = 0, nf = 0;
+        if (i < nitems) {
+            for (int r = 0; r < kRegions; ++r) {
+                const u64 cur = cursors[((size_t)i * kRegions + r) * kCursorStride];
+                nv += cur;
+                if (cur > (u64)rows_limit) flags |= 1u;
+                if (cur > (u64)id_limit) flags |= 2u;
+            }
+            for (int k = 0; k < cpi; ++k) nf += chunk_sum[(size_t)i * cpi + k];
+        }
+        u64 iv = nv, jf = nf;   // inclusive scans over the 64 items of this round
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u64 tv = __shfl_up(iv, o, 64), tf = __shfl_up(jf, o, 64);
+            if (lane >= o) {
+                iv += tv;
+                jf += tf;
+            }
+        }
+        if (i < nitems) {
+            item_offsets[i] = (int64_t)(run_v + iv - nv);
+            item_offsets[nitems + 1 + i] = (int64_t)(run_f + jf - nf);
+        }
+        run_v += readlane64(iv, 63);
+        run_f += readlane64(jf, 63);
+    }
+    const u32 fl = (__ballot(flags & 1u) ? 1u : 0u) | (__ballot(flags & 2u) ? 2u : 0u);
+    if (lane == 0) {
+        item_offsets[nitems] = (int64_t)run_v;
+        item_offsets[2 * nitems + 1] = (int64_t)run_f;
+        hdr[H_V] = run_v;
+        hdr[H_T] = run_f;
+        hdr[H_FLAGS] = fl;
+        hdr[H_RECFORM] = 1ull;
+        mb_publish_v(mb, seq, run_v, fl);
+        mb_publish_f(mb, seq, run_f);
+    }
+}
+
 // Triangle counts.  A block owns a CHUNK = one tile column over `xw` consecutive planes and walks it along x: every
 // sign word is loaded once per chunk (plane x+1 of one step is plane x of the next; all loads of a sub-batch of PB
 // planes are issued together).  Lane = unit: the 8 corner signs of the unit's 64 cells are 8 words (the four column
@@ -642,7 +649,7 @@ __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr
 #endif
 template <int PB>
 __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restrict__ bits, Dims d, int64_t tpp, int xw,
-                                                            u32* __restrict__ chunk_sum, u32* __restrict__ wave_off,
+                                                            int cpi, u32* __restrict__ chunk_sum, u32* __restrict__ wave_off,
                                                             u32* __restrict__ tile_tris, CompactArgs cp,
                                                             u64* __restrict__ hdr) {
     if ((int)blockIdx.x < cp.nblocks) {  // the launch's first blocks move vertices (uniform per block)
@@ -653,13 +660,14 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t chunk = (int64_t)blockIdx.x - cp.nblocks;
     // chunks are numbered item by item (a single grid is one item): cpi chunks each, none straddles two items
-    const int64_t cpi = d.xper > 1 ? ((d.xper - 1 + xw - 1) / xw) * tpp : 1;
-    const int64_t item = chunk / cpi, cl = chunk - item * cpi;
-    const int64_t xc = cl / tpp, tile = cl - xc * tpp;
+    // (32-bit arithmetic; the item split only for a stack)
+    const u32 item = d.stack ? (u32)chunk / (u32)cpi : 0u;
+    const u32 cl = (u32)chunk - item * (u32)cpi;
+    const int64_t xc = cl / (u32)tpp, tile = cl - (u32)xc * (u32)tpp;
     const int64_t x_begin = item * d.xper + xc * xw;
     const int64_t x_end = min(x_begin + xw, item * d.xper + d.xper - 1);  // cell layers [x_begin, x_end)
     const int64_t p = tile * kBlock + tid;
-    const int64_t y = p / d.ncz;
+    const int64_t y = (u32)p / (u32)d.ncz;
     const int c = (int)(p - y * d.ncz);
     const bool valid = (p < d.P) && (y + 1 < d.ry);
     const bool more = c + 1 < d.ncz;
@@ -846,7 +854,7 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     if (XLATE && wave == 0) {  // dense base of every region = exclusive prefix over the region cursors
         if (a.xlate == 1) {
             // (a stack of items: the cursor block of this tile's item; vertex ids are local to the item)
-            const int64_t it = (((int64_t)blockIdx.x - cp.nblocks) / a.tpp) / d.xper;
+            const u32 it = d.stack ? (((u32)blockIdx.x - (u32)cp.nblocks) / (u32)a.tpp) / (u32)d.xper : 0u;
             const u32 cnt = lane < kRegions ? (u32)a.cursors[(size_t)it * kCursorBlockWords + lane * kCursorStride] : 0u;
             const u32 inc = wave_prefix_sum(cnt);
             if (lane < kRegions) s_pref[lane] = inc - cnt;
@@ -856,14 +864,17 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     }
     auto dense = [&](u32 v) -> u32 { return XLATE ? (v & 0x3ffffffu) + s_pref[(v >> 26) & (kRegions - 1)] : v; };
 
-    const int64_t b = (int64_t)blockIdx.x - cp.nblocks;
-    const int64_t x = b / a.tpp;
-    const int64_t tile = b - x * a.tpp;
-    const int64_t item = x / d.xper, xl = x - item * d.xper;
-    if (xl == d.xper - 1) return;   // the last plane of an item has no cell layer above it (stack of items only)
-    const u32 my_tris = a.tile_tris[b];   // (the loads below are issued before this value is looked at)
+    // (32-bit index arithmetic: a 64-bit division costs more than a hundred instructions per wave)
+    const u32 b = (u32)blockIdx.x - (u32)cp.nblocks;
+    const u32 x32 = b / (u32)a.tpp;
+    const int64_t x = x32;
+    const int64_t tile = b - x32 * (u32)a.tpp;
+    const u32 item = d.stack ? x32 / (u32)d.xper : 0u;
+    const u32 xl = x32 - item * (u32)d.xper;
+    if (xl == (u32)d.xper - 1u) return;   // the last plane of an item has no cell layer above it (stack of items only)
+    const u32 my_tris = a.tile_tris[b];
     const int64_t p = tile * kBlock + tid;
-    const int64_t y = p / d.ncz;
+    const int64_t y = (u32)p / (u32)d.ncz;   // (p < 2^31: check_dims)
     const int c = (int)(p - y * d.ncz);
     const bool valid = (p < d.P) && (y + 1 < d.ry);  // x+1 < rx by grid construction
     const bool more = c + 1 < d.ncz;
@@ -871,50 +882,31 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     // phase A: the units [tile start, +256) of planes x and x+1, the same ranges one row up (y+1: "+ncz" units, or a
     // second range of 256 when a row is longer than NHALO chunks), and one unit more (the z+1 neighbour of the last).
     // A cell's four columns W00,W10,W11,W01 are then plane 0/1 at index t and t + hoff.
-    // All global loads of the prologue are issued back to back (one memory round trip): the tile's triangle count,
-    // the staged words and records, and this thread's share of the chunk totals.
+    if (my_tris == 0u) return;  // nothing to emit here (block-uniform; most tiles of a sparse field)
     const bool one_range = d.ncz <= NHALO;
     const int hoff = one_range ? d.ncz : kBlock + 1;   // index distance of the y+1 column
     const int nstage = one_range ? kBlock + d.ncz + 1 : 2 * (kBlock + 1);
     const int64_t p0 = tile * kBlock;
-    constexpr int NST = (NS + kBlock - 1) / kBlock;   // staged entries per thread
-    u64 st_w0[NST], st_w1[NST];
-    uint2 st_r0[NST], st_r1[NST];
-#pragma unroll
-    for (int q = 0; q < NST; ++q) {
-        const int i = tid + q * kBlock;
-        st_w0[q] = st_w1[q] = 0ull;
-        st_r0[q] = st_r1[q] = make_uint2(0u, 0u);
-        if (i < nstage) {
-            const int64_t pi = (one_range || i <= kBlock) ? p0 + i : p0 + d.ncz + (i - kBlock - 1);
-            if (pi < d.P) {
-                const int64_t ui = x * d.P + pi;
-                st_w0[q] = bits[ui];
-                st_w1[q] = bits[ui + d.P];
-                st_r0[q] = rec[ui];  // only entries of units that own vertices are meaningful
-                st_r1[q] = rec[ui + d.P];
-            }
+    for (int i = tid; i < nstage; i += kBlock) {
+        const int64_t pi = (one_range || i <= kBlock) ? p0 + i : p0 + d.ncz + (i - kBlock - 1);
+        const bool ex = pi < d.P;
+        const int64_t ui = x * d.P + pi;
+        s_w[0][i] = ex ? bits[ui] : 0ull;
+        s_w[1][i] = ex ? bits[ui + d.P] : 0ull;
+        if (ex) {
+            s_r[0][i] = rec[ui];  // only entries of units that own vertices are meaningful
+            s_r[1][i] = rec[ui + d.P];
         }
     }
-    // faces of the chunks before this tile's chunk (summed by the whole block)
-    u32 cs = 0;
+    // faces of the chunks before this tile's chunk (summed by the whole block, or looked up)
     {
-        const int64_t cpi = d.xper > 1 ? ((d.xper - 1 + a.xw - 1) / a.xw) * a.tpp : 1;
-        const int64_t mychunk = item * cpi + (xl / a.xw) * a.tpp + tile;
-        for (int64_t i = tid; i < mychunk; i += kBlock) cs += a.chunk_sum[i];
-    }
-    if (my_tris == 0u) return;  // nothing to emit here (block-uniform; most tiles of a sparse field)
-#pragma unroll
-    for (int q = 0; q < NST; ++q) {
-        const int i = tid + q * kBlock;
-        if (i < nstage) {
-            s_w[0][i] = st_w0[q];
-            s_w[1][i] = st_w1[q];
-            s_r[0][i] = st_r0[q];
-            s_r[1][i] = st_r1[q];
+        const int64_t mychunk = (int64_t)(item * (u32)a.cpi + (xl / (u32)a.xw) * (u32)a.tpp) + tile;
+        u32 cs = 0;
+        if (a.chunk_pre) {
+            if (tid == 0) cs = a.chunk_pre[mychunk];
+        } else {
+            for (int64_t i = tid; i < mychunk; i += kBlock) cs += a.chunk_sum[i];
         }
-    }
-    {
         cs = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum(cs), 63);
         if (lane == 0) s_tmp[wave] = cs;
     }
@@ -1316,7 +1308,7 @@ int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3
     if (w.nchunks > 0) {
         StageTimer tm(ST_FACES_COUNT, st);
         const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr, 1u << 26, 1, nullptr};
-        hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)w.nchunks), dim3(kBlock), 0, st, bits, d, w.tpp, w.xw, csum,
+        hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)w.nchunks), dim3(kBlock), 0, st, bits, d, w.tpp, w.xw, (int)w.cpi, csum,
                            woff, (u32*)(ws + w.tile_tris), none, hdr);
     }
     {
@@ -1350,8 +1342,8 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
     if (w.nb_f > 0 && capf > 0) {
         StageTimer tm(ST_EMIT_FACES, st);
         const FaceArgs a{2, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
-                         slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw,
-                         (const u32*)(ws + w.chunk_sum), (const u32*)(ws + w.wave_off),
+                         slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw, (int)w.cpi,
+                         (const u32*)(ws + w.chunk_sum), nullptr, (const u32*)(ws + w.wave_off),
                          (const u32*)(ws + w.tile_tris), nullptr, nullptr, 0};
         const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr, 1u << 26, 1, nullptr};
         launch_faces(d, w, bits, rec, a, none, hdr, faces, capf, true, st);
@@ -1522,7 +1514,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         const CompactArgs cpe{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, early * kRegions, 0, nparts, 0,
                               csum, (int)w.nchunks, cursors, id_limit, 1, nullptr};
         hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)(w.nchunks + cpe.nblocks)), dim3(kBlock), 0, st, bits,
-                           d, w.tpp, w.xw, csum, woff, (u32*)(ws + w.tile_tris), cpe, hdr);
+                           d, w.tpp, w.xw, (int)w.cpi, csum, woff, (u32*)(ws + w.tile_tris), cpe, hdr);
     }
     if (part == 4) {  // totals to the host now; the faces (and the rest of the vertex copy) follow in part 5
         StageTimer tm(ST_SCAN_F, st);
@@ -1531,8 +1523,8 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         return P3D_OK;
     }
     const FaceArgs a{1, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
-                     slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw,
-                     csum, woff, (const u32*)(ws + w.tile_tris), cursors, mb, seq};
+                     slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw, (int)w.cpi,
+                     csum, nullptr, woff, (const u32*)(ws + w.tile_tris), cursors, mb, seq};
     const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, (nparts - early) * kRegions, early,
                          nparts, part == 5 ? 0 : 1, csum, (int)w.nchunks, cursors, id_limit, 1, nullptr};
     StageTimer tm(ST_EMIT_FACES, st);
@@ -1567,19 +1559,33 @@ int fused_stack_impl(const T* grids, const Dims& d, const Ws& w, float thresh, c
     u64 seq = 0;
     u64* mb = mailbox_open(ws, &seq);
     const bool copy = scratch && capv > 0;
-    // compaction blocks: about a thousand for the whole stack, at least one per (item, region)
-    const int nparts = copy ? std::max(1, std::min(8, 1024 / (kRegions * d.nitems))) : 1;
-    const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr, 1u << 26, 1, nullptr};
+    // compaction blocks: every (item, region) is copied in `nparts` slices, `early` of them by blocks riding in the
+    // counting launch (VALU-bound, HBM idle), the rest with the faces -- about two thousand blocks for the stack
+    const int nparts = copy ? std::max(2, std::min(8, 2048 / (kRegions * d.nitems))) : 1;
+    const int early = (copy && w.nchunks > 0) ? std::max(1, nparts * 3 / 8) : 0;
     if (w.nchunks > 0) {
         StageTimer tm(ST_FACES_COUNT, st);
-        hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)w.nchunks), dim3(kBlock), 0, st, bits, d, w.tpp,
-                           w.xw, csum, woff, (u32*)(ws + w.tile_tris), none, hdr);
+        const CompactArgs cpe{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, early * kRegions * d.nitems, 0,
+                              nparts, 0, csum, (int)w.nchunks, cursors, id_limit, d.nitems, item_offsets};
+        hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)(w.nchunks + cpe.nblocks)), dim3(kBlock), 0, st, bits,
+                           d, w.tpp, w.xw, (int)w.cpi, csum, woff, (u32*)(ws + w.tile_tris), cpe, hdr);
     }
-    const FaceArgs a{1, 0, 0, 0, nullptr, 0, w.tpp, w.xw, csum, woff, (const u32*)(ws + w.tile_tris), cursors, mb, seq};
-    const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, nparts * kRegions * d.nitems, 0,
-                         nparts, 1, csum, (int)w.nchunks, cursors, id_limit, d.nitems, item_offsets};
-    StageTimer tm(ST_EMIT_FACES, st);
-    launch_faces(d, w, bits, rec, a, cp, hdr, faces, capf, w.nb_f > 0 && capf > 0, st);
+    // exclusive prefix of the chunk totals (the scan arrays of the counting call are free in this mode)
+    u32* cpre = (u32*)(ws + w.bbase_v);
+    const bool use_pre = w.nchunks > 1024;   // (<= 4096 chunks: the scan's padded runs fit the arrays, see make_ws)
+    if (use_pre)
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, csum, cpre, w.nchunks, hdr + H_T, nullptr, 0ull, 1);
+    const FaceArgs a{1, 0, 0, 0, nullptr, 0, w.tpp, w.xw, (int)w.cpi, csum, use_pre ? cpre : nullptr, woff,
+                     (const u32*)(ws + w.tile_tris), cursors, nullptr, 0};
+    const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows,
+                         (nparts - early) * kRegions * d.nitems, early, nparts, 0, csum, (int)w.nchunks, cursors, id_limit,
+                         d.nitems, item_offsets};
+    {
+        StageTimer tm(ST_EMIT_FACES, st);
+        launch_faces(d, w, bits, rec, a, cp, hdr, faces, capf, w.nb_f > 0 && capf > 0, st);
+    }
+    hipLaunchKernelGGL(k_stack_finish, dim3(1), dim3(64), 0, st, cursors, csum, (int)w.nchunks, d.nitems,
+                       scratch ? store_rows : region_rows, id_limit, item_offsets, hdr, mb, seq);
     HIP_TRY(hipGetLastError());
     return P3D_OK;
 }
