@@ -44,7 +44,7 @@ def soup_hashes(v, f):
     return torch.sort(h).values, vkey
 
 
-def cpu_baseline(grid, thresh, lower, upper, out_v, out_f):
+def cpu_baseline(grid, thresh, lower, upper, out_v, out_f, budget=(8.0, 6.0)):
     """The CPU leg (rank 0, N=1): the oracle restatement of the reference kernels (`kind: "port"`) timed on the host
     cores next to the GPU number -- one thread and all cores (OpenMP over axis-0 planes) -- and, when PyMCubes is
     importable, the reference's own CPU path `mcubes.marching_cubes` (marching_cubes.py:74; `kind: "reference"`).
@@ -56,13 +56,13 @@ def cpu_baseline(grid, thresh, lower, upper, out_v, out_f):
     nvox = rx * ry * rz
     g = grid.cpu().numpy()
     counts = oracle_count(g, thresh)
-    # bounded sample: whole extractions of the same grid, ~8 s of single-thread work, then ~6 s on all cores
+    # bounded sample: whole extractions of the same grid, ~8 s of single-thread work, then ~6 s on all cores (default)
     reps1, c0 = 0, time.perf_counter()
     while True:
         ov, of, _ = oracle_extract(g, thresh, lower, upper, counts=counts, want_keys=False)
         reps1 += 1
         c1 = time.perf_counter()
-        if c1 - c0 >= 8.0 or reps1 >= 8:
+        if c1 - c0 >= budget[0] or reps1 >= 8:
             break
     t1 = (c1 - c0) / reps1
     repsn, c0 = 0, time.perf_counter()
@@ -70,7 +70,7 @@ def cpu_baseline(grid, thresh, lower, upper, out_v, out_f):
         mv, mf, _ = oracle_extract(g, thresh, lower, upper, threads=0, counts=counts, want_keys=False)
         repsn += 1
         c1 = time.perf_counter()
-        if c1 - c0 >= 6.0 or repsn >= 32:
+        if c1 - c0 >= budget[1] or repsn >= 32:
             break
     tn = (c1 - c0) / repsn
     nthreads = int(getattr(oracle_extract, "last_threads", 1))
@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=0, help="override: cubic grid of this size (N=1 only)")
+    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4", "c5"],
+                    help="N=1 workload (BASELINE.json configs): c2 = 256^3 bunny SDF fp32, c3 = 512^3 Perlin fp32 (the "
+                         "headline; default), c4 = the 1024^3 volume on one GPU, c5 = batch of 32 x 256^3 fp16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="also print per-stage hipEvent times to stderr")
     args = ap.parse_args()
@@ -142,8 +145,12 @@ def main():
     from primitive3d_amd import capi
     from primitive3d_amd.fields import perlin_grid
 
+    batch = 1
     if world == 1:
-        shape = (args.size,) * 3 if args.size else SHAPES[1]
+        shape = (args.size,) * 3 if args.size else {"c2": (256,) * 3, "c3": SHAPES[1], "c4": (1024,) * 3,
+                                                     "c5": (256,) * 3}[args.config]
+        if args.config == "c5":
+            batch = 32 if not args.size else 4
     else:
         if world not in SHAPES:
             sys.exit(f"unsupported world size {world}")
@@ -154,7 +161,28 @@ def main():
     thresh = 0.0
     lower, upper = [0.0, 0.0, 0.0], [float(rx), float(ry), float(rz)]
 
-    if world == 1:
+    workload = f"{rx}x{ry}x{rz} fp32 single-octave Perlin SDF (period 64, seed 0), iso 0"
+    sizeof = 4
+    if world == 1 and args.config == "c5":
+        # BASELINE.json configs[4]: per-frame density grids, fp16 in memory (compared in fp32: the up-cast is exact)
+        grid = torch.stack([perlin_grid(shape, period=64, seed=s, device=dev).half() for s in range(batch)])
+        sizeof = 2
+        workload = (f"batch of {batch} x {rx}x{ry}x{rz} fp16 Perlin SDF grids (period 64, seeds 0..{batch - 1}), iso 0, "
+                    f"one marching_cubes_batched call per step")
+
+        def step():
+            return p3d.marching_cubes_batched(grid, thresh)[:2]
+    elif world == 1 and args.config == "c2" and not args.size:
+        # BASELINE.json configs[1] as SURVEY.md 8d defines it: the reference's 66^3 bunny SDF resampled to 256^3
+        import numpy as np
+        b66 = torch.from_numpy(np.load(ROOT / "tests" / "golden" / "bunny66.npy"))
+        grid = torch.nn.functional.interpolate(b66[None, None], size=shape, mode="trilinear", align_corners=True)[0, 0]
+        grid = grid.contiguous().to(dev)
+        workload = "256x256x256 fp32 bunny SDF (examples/data/bunny.npy trilinearly resampled from 66^3), iso 0"
+
+        def step():
+            return p3d.libPrim3D.marching_cubes(grid, thresh, lower, upper)
+    elif world == 1:
         grid = perlin_grid(shape, period=64, seed=0, device=dev)
 
         def step():
@@ -217,7 +245,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    nvox_total = rx * ry * rz
+    nvox_total = rx * ry * rz * batch
     ms_per_step = elapsed / args.steps * 1e3
     value = nvox_total * args.steps / elapsed / 1e6
 
@@ -231,12 +259,12 @@ def main():
     if rank == 0:
         # roofline of the dominant kernel: algorithmic bytes = the field read once
         local_vox = nvox_total // world
-        alg_bytes = local_vox * 4
+        alg_bytes = local_vox * sizeof
         avg_ms = sum(dom_ms) / len(dom_ms)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         tfile = ROOT / "profiles" / "traffic.json"
-        if tfile.exists() and world == 1 and shape == SHAPES[1]:  # measured for this exact workload only
+        if tfile.exists() and world == 1 and shape == SHAPES[1] and batch == 1 and args.config == "c3":  # this workload only
             try:
                 traffic = json.loads(tfile.read_text()).get("k_fused_hbm_bytes_per_launch")
             except Exception:
@@ -252,19 +280,35 @@ def main():
             print("stage ms/step:", {k: round(v / args.steps, 4) for k, v in stage_acc.items()}, file=sys.stderr)
 
         line = {
-            "metric": f"Mvoxels/s on {rx}x{ry}x{rz} fp32 SDF (whole marching_cubes call, device-resident grid)"
-                      if (rx, ry, rz) != (512, 512, 512) else
-                      "Mvoxels/s on 512^3 fp32 SDF (whole marching_cubes call, device-resident grid)",
+            "metric": "Mvoxels/s on 512^3 fp32 SDF (whole marching_cubes call, device-resident grid)"
+                      if (rx, ry, rz, batch) == (512, 512, 512, 1) else
+                      f"Mvoxels/s on {'%d x ' % batch if batch > 1 else ''}{rx}x{ry}x{rz} "
+                      f"{'fp16' if sizeof == 2 else 'fp32'} SDF (whole marching_cubes call, device-resident grid)",
             "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{rx}x{ry}x{rz} fp32 single-octave Perlin SDF (period 64, seed 0), iso 0",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16" if sizeof == 2 else "f32", "data": "synthetic",
+            "config": {"workload": workload,
                        "voxels_per_gpu": local_vox, "vertices": nv, "faces": nf,
                        "partition": "none" if world == 1 else f"axis-0 slabs x{world}, 1-plane RCCL halo"},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(grid, thresh, lower, upper, out_v, out_f)
+            if batch > 1:   # bounded sample: the first items of the batch, each compared with the GPU's mesh of that item
+                v_all, f_all, vo, fo = p3d.marching_cubes_batched(grid, thresh)
+                torch.cuda.synchronize()
+                vo, fo = vo.cpu(), fo.cpu()
+                nsample = min(batch, 4)
+                res = None
+                for b in range(nsample):
+                    r = cpu_baseline(grid[b].float(), thresh, lower, upper, v_all[vo[b]:vo[b + 1]], f_all[fo[b]:fo[b + 1]],
+                                     budget=(2.0, 1.5))
+                    res = r if res is None else res
+                res["sample"] = (f"items 0..{nsample - 1} of the batch, each extracted repeatedly by oracle/mc_oracle.c "
+                                 f"(first item's rates reported) and compared with the GPU's mesh of that item; "
+                                 + res["sample"])
+                line["cpu_baseline"] = res
+            else:
+                line["cpu_baseline"] = cpu_baseline(grid, thresh, lower, upper, out_v, out_f)
         print(json.dumps(line))
     if world > 1 and args.stages:
         # per-phase GPU time of the LAST step on every rank (halo wait, all-gather, record exchange, ...): what the first

@@ -586,52 +586,60 @@ __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr
     for (; i < nvec; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(s4 + i), d4 + i);
 }
 
-// Totals, flags and per-item offsets of a stack of items (one wave; launched after the face kernel of a batched call).
+// Totals, flags and per-item offsets of a stack of items (one block of 1024 threads, launched after the face kernel of a
+// batched call): 32 lanes per item add up its 32 cursors and its chunk totals, thread 0 then walks the items.
 // item_offsets: [nitems + 1] vertex offsets, then [nitems + 1] face offsets.
-__global__ void k_stack_finish(const u64* __restrict__ cursors, const u32* __restrict__ chunk_sum, int nchunks, int nitems,
-                               u32 rows_limit, u32 id_limit, int64_t* __restrict__ item_offsets, u64* __restrict__ hdr,
-                               u64* mb, u64 seq) {
-    const int lane = threadIdx.x;
+__global__ void __launch_bounds__(1024) k_stack_finish(const u64* __restrict__ cursors, const u32* __restrict__ chunk_sum,
+                                                       int nchunks, int nitems, u32 rows_limit, u32 id_limit,
+                                                       int64_t* __restrict__ item_offsets, u64* __restrict__ hdr, u64* mb,
+                                                       u64 seq) {
+    __shared__ u64 s_nv[32], s_nf[32];
+    __shared__ u32 s_fl[32];
+    const int tid = threadIdx.x, sub = tid & 31, grp = tid >> 5;   // 32 groups of 32 lanes
     const int cpi = nchunks / nitems;
     u64 run_v = 0, run_f = 0;
-    u32 flags = 0;
-    for (int i0 = 0; i0 < nitems; i0 += 64) {   // lane l takes items l, l + 64, ...
-        const int i = i0 + lane;
+    u32 run_fl = 0;
+    for (int i0 = 0; i0 < nitems; i0 += 32) {
+        const int i = i0 + grp;
         u64 nv = 0, nf = 0;
+        u32 fl = 0;
         if (i < nitems) {
-            for (int r = 0; r < kRegions; ++r) {
-                const u64 cur = cursors[((size_t)i * kRegions + r) * kCursorStride];
-                nv += cur;
-                if (cur > (u64)rows_limit) flags |= 1u;
-                if (cur > (u64)id_limit) flags |= 2u;
-            }
-            for (int k = 0; k < cpi; ++k) nf += chunk_sum[(size_t)i * cpi + k];
+            const u64 cur = cursors[((size_t)i * kRegions + sub) * kCursorStride];
+            nv = cur;
+            fl = (cur > (u64)rows_limit ? 1u : 0u) | (cur > (u64)id_limit ? 2u : 0u);
+            for (int k = sub; k < cpi; k += 32) nf += chunk_sum[(size_t)i * cpi + k];
         }
-        u64 iv = nv, jf = nf;   // inclusive scans over the 64 items of this round
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const u64 tv = __shfl_up(iv, o, 64), tf = __shfl_up(jf, o, 64);
-            if (lane >= o) {
-                iv += tv;
-                jf += tf;
+        for (int o = 16; o > 0; o >>= 1) {   // (xor butterflies stay inside each half wave)
+            nv += __shfl_xor(nv, o, 64);
+            nf += __shfl_xor(nf, o, 64);
+            fl |= (u32)__shfl_xor((int)fl, o, 64);
+        }
+        if (sub == 0) {
+            s_nv[grp] = nv;
+            s_nf[grp] = nf;
+            s_fl[grp] = fl;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int k = 0; k < 32 && i0 + k < nitems; ++k) {
+                item_offsets[i0 + k] = (int64_t)run_v;
+                item_offsets[nitems + 1 + i0 + k] = (int64_t)run_f;
+                run_v += s_nv[k];
+                run_f += s_nf[k];
+                run_fl |= s_fl[k];
             }
         }
-        if (i < nitems) {
-            item_offsets[i] = (int64_t)(run_v + iv - nv);
-            item_offsets[nitems + 1 + i] = (int64_t)(run_f + jf - nf);
-        }
-        run_v += readlane64(iv, 63);
-        run_f += readlane64(jf, 63);
+        __syncthreads();
     }
-    const u32 fl = (__ballot(flags & 1u) ? 1u : 0u) | (__ballot(flags & 2u) ? 2u : 0u);
-    if (lane == 0) {
+    if (tid == 0) {
         item_offsets[nitems] = (int64_t)run_v;
         item_offsets[2 * nitems + 1] = (int64_t)run_f;
         hdr[H_V] = run_v;
         hdr[H_T] = run_f;
-        hdr[H_FLAGS] = fl;
+        hdr[H_FLAGS] = run_fl;
         hdr[H_RECFORM] = 1ull;
-        mb_publish_v(mb, seq, run_v, fl);
+        mb_publish_v(mb, seq, run_v, run_fl);
         mb_publish_f(mb, seq, run_f);
     }
 }
@@ -1584,7 +1592,7 @@ int fused_stack_impl(const T* grids, const Dims& d, const Ws& w, float thresh, c
         StageTimer tm(ST_EMIT_FACES, st);
         launch_faces(d, w, bits, rec, a, cp, hdr, faces, capf, w.nb_f > 0 && capf > 0, st);
     }
-    hipLaunchKernelGGL(k_stack_finish, dim3(1), dim3(64), 0, st, cursors, csum, (int)w.nchunks, d.nitems,
+    hipLaunchKernelGGL(k_stack_finish, dim3(1), dim3(1024), 0, st, cursors, csum, (int)w.nchunks, d.nitems,
                        scratch ? store_rows : region_rows, id_limit, item_offsets, hdr, mb, seq);
     HIP_TRY(hipGetLastError());
     return P3D_OK;

@@ -7,7 +7,7 @@ import sys
 from collections import defaultdict
 
 d = sys.argv[1]
-ours = ("k_fused", "k_face_count_walk", "k_face_total", "k_faces", "k_export_plane_records", "k_scan_blocks", "k_classify",
+ours = ("k_fused", "k_face_count_walk", "k_face_total", "k_faces", "k_stack_finish", "k_export_plane_records", "k_scan_blocks", "k_classify",
         "k_unit_counts", "k_unit_records", "k_emit_vertices", "k_fix_records")
 
 
@@ -18,19 +18,23 @@ def short(name):
     return None
 
 
-rows = []
-for f in glob.glob(d + "/stats/**/*kernel_stats.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        rows.append(r)
-print("== rocprofv3 --kernel-trace --stats (our kernels; ns)")
-keep = [r for r in rows if short(r["Name"])]
-for r in sorted(keep, key=lambda r: -float(r["TotalDurationNs"])):
-    print(f'{short(r["Name"]):22s} calls={r["Calls"]:>4s} avg={float(r["AverageNs"]):10.0f} min={r["MinNs"]:>8s} max={r["MaxNs"]:>8s}')
-with open(d + "/kernel_stats_ours.csv", "w") as fo:
-    w = csv.writer(fo)
-    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
-    for r in keep:
-        w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+for sub, label in (("stats", "headline c3"), ("stats_c5", "c5 batch"), ("stats_c2", "c2 bunny")):
+    rows = []
+    for f in glob.glob(d + f"/{sub}/**/*kernel_stats.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            rows.append(r)
+    if not rows:
+        continue
+    print(f"== rocprofv3 --kernel-trace --stats, {label} (our kernels; ns)")
+    keep = [r for r in rows if short(r["Name"])]
+    for r in sorted(keep, key=lambda r: -float(r["TotalDurationNs"])):
+        print(f'{short(r["Name"]):22s} calls={r["Calls"]:>4s} avg={float(r["AverageNs"]):10.0f} min={r["MinNs"]:>8s} max={r["MaxNs"]:>8s}')
+    name = "kernel_stats_ours.csv" if sub == "stats" else f"kernel_{sub}_ours.csv"
+    with open(d + "/" + name, "w") as fo:
+        w = csv.writer(fo)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
+        for r in keep:
+            w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
 
 
 def counter(sub, cname):
