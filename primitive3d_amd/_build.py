@@ -88,10 +88,31 @@ def build_pybind(force: bool = False, verbose: bool = False) -> Path:
     return out
 
 
+def mt_path() -> Path:
+    return PKG / "libp3dmt.so"
+
+
+def build_mt(force: bool = False, verbose: bool = False) -> Path:
+    """libp3dmt.so: marching tetrahedra (include/p3d_mt.h), HIP kernels around rocPRIM's sort and scans."""
+    out = mt_path()
+    deps = [CSRC / "p3d_mt.hip", ROOT / "include" / "p3d_mt.h"]
+    if force or _stale(out, deps):
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+               # the reference's interpolation is two separately rounded products and a sum (marching_tetrahedras.py:188)
+               "-ffp-contract=off", "-Wall", "-Wextra", "-Wno-unused-parameter",
+               str(CSRC / "p3d_mt.hip"), "-o", str(out)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        _write_stamp(out, deps)
+    return out
+
+
 def build_all(force: bool = False, verbose: bool = False):
     a = build_capi(force, verbose)
     b = build_pybind(force, verbose)
-    return a, b
+    c = build_mt(force, verbose)
+    return a, b, c
 
 
 if __name__ == "__main__":

@@ -7,8 +7,8 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def declared_functions():
-    text = (ROOT / "include" / "p3d_mc.h").read_text()
+def declared_functions(header="p3d_mc.h"):
+    text = (ROOT / "include" / header).read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(p3d_[a-z0-9_]+)\s*\(", text)))
 
@@ -22,6 +22,22 @@ def test_header_functions_are_exported(built):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/p3d_mc.h but not exported"
     assert sorted(capi.SYMBOLS) == names, "capi.py binds exactly the declared entry points"
+
+
+def test_tetrahedra_header_functions_are_exported(built):
+    """include/p3d_mt.h <-> libp3dmt.so <-> the ctypes binding (no compute calls without a GPU)."""
+    from primitive3d_amd import tetrahedra
+    from primitive3d_amd._build import mt_path
+    lib = ctypes.CDLL(str(mt_path()))
+    names = declared_functions("p3d_mt.h")
+    assert len(names) == 5
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/p3d_mt.h but not exported"
+    assert sorted(tetrahedra.SYMBOLS) == names
+    assert tetrahedra.lib().p3d_mt_abi_version() == 1
+    nbytes = ctypes.c_size_t(0)
+    assert tetrahedra.lib().p3d_mt_workspace_bytes(2056, 12045, ctypes.byref(nbytes)) == 0 and nbytes.value > 12045 * 200
+    assert tetrahedra.lib().p3d_mt_workspace_bytes(1 << 33, 4, ctypes.byref(nbytes)) < 0
 
 
 def test_host_only_entry_points(built):

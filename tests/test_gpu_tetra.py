@@ -1,0 +1,98 @@
+"""GPU parity of the HIP marching tetrahedra (libp3dmt.so, through the reference-shaped wrapper) against outputs of
+the REFERENCE itself (tests/golden/tetra_*.npz) and against the oracle restatement on larger seeded meshes."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.mt_oracle import mt_oracle
+
+pytestmark = pytest.mark.gpu
+GOLD = sorted((Path(__file__).parent / "golden").glob("tetra_*.npz"))
+TOL = 1e-6  # positions are asserted bit-identical; TOL only words the failure message
+
+
+def _same(v, f, ti, ta, ref_v, ref_f, ref_ti, ref_ta):
+    assert np.array_equal(ta, ref_ta), "orientation fix differs"
+    assert np.array_equal(f, ref_f), "faces differ"
+    assert np.array_equal(ti, ref_ti), "tet indices differ"
+    assert v.shape == ref_v.shape
+    if not np.array_equal(v, ref_v):
+        d = np.abs(v.astype(np.float64) - ref_v).max()
+        pytest.fail(f"vertex positions differ by {d} (tolerance for information: {TOL})")
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[p.stem for p in GOLD])
+@pytest.mark.parametrize("where", ["cuda", "cpu"])
+def test_reference_vectors(gpu, built, path, where):
+    g = np.load(path)
+    dev = gpu if where == "cuda" else torch.device("cpu")
+    tets = torch.from_numpy(g["tets"].copy()).to(dev)
+    v, f, ti = built.marching_tetrahedras(torch.from_numpy(g["points"]).to(dev), tets, torch.from_numpy(g["sdf"]).to(dev), True)
+    assert v.device.type == where and f.dtype == torch.int64 and v.dtype == torch.float32
+    _same(v.cpu().numpy(), f.cpu().numpy(), ti.cpu().numpy(), tets.cpu().numpy(), g["verts"], g["faces"], g["tet_idx"],
+          g["tets_after"])
+    v2, f2 = built.marching_tetrahedras(torch.from_numpy(g["points"]).to(dev), tets, torch.from_numpy(g["sdf"]).to(dev))
+    assert torch.equal(v2, v) and torch.equal(f2, f)   # (tets are already oriented now: idempotent)
+
+
+def _grid_tets(n, seed):
+    """n^3 cubes of 5 tetrahedra each on a jittered lattice (an SDF-friendly mesh with hundreds of thousands of tets)."""
+    rng = np.random.default_rng(seed)
+    ax = np.arange(n + 1)
+    P = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    P += rng.uniform(-0.2, 0.2, P.shape).astype(np.float32)
+    idx = lambda x, y, z: (x * (n + 1) + y) * (n + 1) + z
+    c = np.stack(np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij"), -1).reshape(-1, 3)
+    x, y, z = c[:, 0], c[:, 1], c[:, 2]
+    v = [idx(x + dx, y + dy, z + dz) for dx in (0, 1) for dy in (0, 1) for dz in (0, 1)]   # v[4dx+2dy+dz]
+    par = ((x + y + z) % 2 == 0)
+    A = [(0, 3, 5, 6), (0, 1, 3, 5), (0, 2, 3, 6), (0, 4, 5, 6), (3, 5, 6, 7)]
+    B = [(1, 2, 4, 7), (0, 1, 2, 4), (1, 2, 3, 7), (1, 4, 5, 7), (2, 4, 6, 7)]
+    tets = []
+    for ta, tb in zip(A, B):
+        tets.append(np.where(par[:, None], np.stack([v[k] for k in ta], 1), np.stack([v[k] for k in tb], 1)))
+    T = np.concatenate(tets).astype(np.int64)
+    T = T[rng.permutation(len(T))]
+    sdf = (np.linalg.norm(P - n / 2, axis=1) - n / 3 + 0.3 * np.sin(P[:, 0])).astype(np.float32)
+    return P, T, sdf
+
+
+@pytest.mark.parametrize("n", [12, 40])
+def test_lattice_meshes_match_the_oracle(gpu, built, n):
+    P, T, sdf = _grid_tets(n, n)
+    tets = torch.from_numpy(T.copy()).to(gpu)
+    v, f, ti = built.marching_tetrahedras(torch.from_numpy(P).to(gpu), tets, torch.from_numpy(sdf).to(gpu), True)
+    rv, rf, rti, rta = mt_oracle(P, T, sdf)
+    _same(v.cpu().numpy(), f.cpu().numpy(), ti.cpu().numpy(), tets.cpu().numpy(), rv, rf, rti, rta)
+    assert f.numel() == 0 or (int(f.min()) >= 0 and int(f.max()) < v.shape[0])
+
+
+def test_gradients_flow_like_the_reference(gpu, built):
+    """vertices and sdf get gradients through the interpolation (:178-190); checked against autograd on the oracle's
+    formula re-done in float64."""
+    g = np.load(Path(__file__).parent / "golden" / "tetra_delaunay_smooth_400.npz")
+    P = torch.from_numpy(g["points"]).to(gpu).requires_grad_(True)
+    S = torch.from_numpy(g["sdf"]).to(gpu).requires_grad_(True)
+    tets = torch.from_numpy(g["tets"].copy()).to(gpu)
+    v, f = built.marching_tetrahedras(P, tets, S)
+    assert v.requires_grad and np.array_equal(f.cpu().numpy(), g["faces"])
+    assert torch.allclose(v.detach().cpu(), torch.from_numpy(g["verts"]), atol=1e-6)
+    (v ** 2).sum().backward()
+    assert P.grad is not None and S.grad is not None and torch.isfinite(P.grad).all() and torch.isfinite(S.grad).all()
+    assert float(P.grad.abs().sum()) > 0 and float(S.grad.abs().sum()) > 0
+
+
+def test_argument_errors(gpu, built):
+    P = torch.zeros(4, 3, device=gpu)
+    T = torch.tensor([[0, 1, 2, 3]], device=gpu)
+    S = torch.zeros(4, device=gpu)
+    with pytest.raises(TypeError):
+        built.marching_tetrahedras(P.double(), T, S)
+    with pytest.raises(TypeError):
+        built.marching_tetrahedras(P, T.int(), S)
+    with pytest.raises(ValueError):
+        built.marching_tetrahedras(P, T[:, :3], S)
+    v, f = built.marching_tetrahedras(P, T, S)
+    assert v.shape == (0, 3) and f.shape == (0, 3)
