@@ -98,8 +98,11 @@ __host__ __device__ inline Dims make_dims_stack(int64_t nitems, int64_t rx, int6
 
 // face chunk = one tile column over this many planes: 8, doubled until there are at most 4096 chunks (every face tile
 // adds up the chunk totals before its own chunk: a few KiB of coalesced reads)
+#ifndef P3D_FACE_XW
+#define P3D_FACE_XW 8
+#endif
 inline int face_chunk_planes(int64_t rx, int64_t tpp, int64_t nitems = 1) {
-    int xw = 8;
+    int xw = P3D_FACE_XW;
     while (((rx - 1 + xw - 1) / xw) * tpp * nitems > 4096) xw *= 2;
     return xw;
 }
@@ -461,6 +464,16 @@ struct FaceArgs {
     u64 seq;
 };
 
+// dev-only: -DP3D_FACES_TIMING accumulates per-phase shader cycles of k_faces (one atomic per wave and phase) into
+// hdr[600 + phase]: 0 prologue up to the barrier, 1 per-unit work + cell list, 2 cell phase (ids), 3 triangle rounds,
+// 4 waves counted
+#ifdef P3D_FACES_TIMING
+#define P3D_T(var) const u64 var = __builtin_readcyclecounter()
+#define P3D_TACC(ph, a_, b_) do { if ((threadIdx.x & 63) == 0) atomicAdd(hdr + 600 + (ph), (u64)((b_) - (a_))); } while (0)
+#else
+#define P3D_T(var)
+#define P3D_TACC(ph, a_, b_)
+#endif
 #ifndef P3D_WAVE_CELLS
 #define P3D_WAVE_CELLS 512
 #endif
@@ -852,25 +865,37 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     __shared__ unsigned char s_nb[kBlock];               // per unit: bit j = sign of column j at the first voxel of the next chunk
     __shared__ unsigned short s_cells[4][kWaveCells];    // per wave: active cells of the round, unit-in-tile << 6 | z
     __shared__ u32 s_ids[4][12][64];                     // per wave: vertex ids of the batch's cells' 12 edges
-    __shared__ u32 s_pref[kRegions];
     __shared__ u32 s_tmp[4];
 
+    P3D_T(t_begin);
     const bool XLATE = a.xlate == 1 || (a.xlate == 2 && hdr[H_RECFORM] != 0ull);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     s_tab[tid] = g_tri_packed[tid];
     s_ntri[tid] = g_tri_count[tid];
-    if (XLATE && wave == 0) {  // dense base of every region = exclusive prefix over the region cursors
+    // dense base of every vertex region = exclusive prefix over the region cursors, kept by EVERY wave in a register
+    // (lane r = base of region r): the records are translated once, when they are staged, not once per cell
+    u32 pref = 0;
+    if (XLATE) {
         if (a.xlate == 1) {
             // (a stack of items: the cursor block of this tile's item; vertex ids are local to the item)
             const u32 it = d.stack ? (((u32)blockIdx.x - (u32)cp.nblocks) / (u32)a.tpp) / (u32)d.xper : 0u;
             const u32 cnt = lane < kRegions ? (u32)a.cursors[(size_t)it * kCursorBlockWords + lane * kCursorStride] : 0u;
-            const u32 inc = wave_prefix_sum(cnt);
-            if (lane < kRegions) s_pref[lane] = inc - cnt;
+            pref = wave_prefix_sum(cnt) - cnt;
         } else if (lane < kRegions) {
-            s_pref[lane] = (u32)hdr[H_PREFIX + lane];
+            pref = (u32)hdr[H_PREFIX + lane];
         }
     }
-    auto dense = [&](u32 v) -> u32 { return XLATE ? (v & 0x3ffffffu) + s_pref[(v >> 26) & (kRegions - 1)] : v; };
+    auto dense = [&](u32 v) -> u32 {
+        return XLATE ? (v & 0x3ffffffu) + (u32)__builtin_amdgcn_ds_bpermute((int)(((v >> 26) & (kRegions - 1)) << 2), (int)pref) : v;
+    };
+    // id bases (a slab of a multi-GPU volume numbers its vertices after the ranks before it)
+    u32 b0 = (u32)a.vid_base, bhalo = (u32)a.halo_vid_base;
+    if (a.rank_counts) {  // uniform: a handful of scalar loads
+        int64_t acc = 0;
+        for (int r = 0; r < a.rank; ++r) acc += a.rank_counts[r];
+        b0 = (u32)acc;
+        bhalo = (u32)(acc + a.rank_counts[a.rank]);
+    }
 
     // (32-bit index arithmetic: a 64-bit division costs more than a hundred instructions per wave)
     const u32 b = (u32)blockIdx.x - (u32)cp.nblocks;
@@ -890,35 +915,64 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     // phase A: the units [tile start, +256) of planes x and x+1, the same ranges one row up (y+1: "+ncz" units, or a
     // second range of 256 when a row is longer than NHALO chunks), and one unit more (the z+1 neighbour of the last).
     // A cell's four columns W00,W10,W11,W01 are then plane 0/1 at index t and t + hoff.
-    if (my_tris == 0u) return;  // nothing to emit here (block-uniform; most tiles of a sparse field)
+    // ALL global loads of the prologue are issued before any of them is waited for -- the tile's triangle count, the
+    // region cursors (above), the staged words and records, this thread's share of the chunk totals: one memory round
+    // trip instead of three dependent ones (measured with -DP3D_FACES_TIMING: the prologue was 58 % of a wave's life).
     const bool one_range = d.ncz <= NHALO;
     const int hoff = one_range ? d.ncz : kBlock + 1;   // index distance of the y+1 column
     const int nstage = one_range ? kBlock + d.ncz + 1 : 2 * (kBlock + 1);
     const int64_t p0 = tile * kBlock;
-    for (int i = tid; i < nstage; i += kBlock) {
+    const bool xhalo = a.halo_last && (x + 1 == d.rx - 1);  // columns 1,2 live in the imported plane
+    constexpr int NST = (NS + kBlock - 1) / kBlock;   // staged entries per thread
+    u64 st_w0[NST], st_w1[NST];
+    uint2 st_r0[NST], st_r1[NST];
+#pragma unroll
+    for (int q = 0; q < NST; ++q) {
+        const int i = tid + q * kBlock;
+        st_w0[q] = st_w1[q] = 0ull;
+        st_r0[q] = st_r1[q] = make_uint2(0u, 0u);
         const int64_t pi = (one_range || i <= kBlock) ? p0 + i : p0 + d.ncz + (i - kBlock - 1);
-        const bool ex = pi < d.P;
-        const int64_t ui = x * d.P + pi;
-        s_w[0][i] = ex ? bits[ui] : 0ull;
-        s_w[1][i] = ex ? bits[ui + d.P] : 0ull;
-        if (ex) {
-            s_r[0][i] = rec[ui];  // only entries of units that own vertices are meaningful
-            s_r[1][i] = rec[ui + d.P];
+        if (i < nstage && pi < d.P) {
+            const int64_t ui = x * d.P + pi;
+            st_w0[q] = bits[ui];
+            st_w1[q] = bits[ui + d.P];
+            st_r0[q] = rec[ui];  // only entries of units that own vertices are meaningful
+            st_r1[q] = rec[ui + d.P];
         }
     }
     // faces of the chunks before this tile's chunk (summed by the whole block, or looked up)
+    u32 cs = 0;
     {
         const int64_t mychunk = (int64_t)(item * (u32)a.cpi + (xl / (u32)a.xw) * (u32)a.tpp) + tile;
-        u32 cs = 0;
         if (a.chunk_pre) {
             if (tid == 0) cs = a.chunk_pre[mychunk];
         } else {
             for (int64_t i = tid; i < mychunk; i += kBlock) cs += a.chunk_sum[i];
         }
+    }
+    if (my_tris == 0u) return;  // nothing to emit here (block-uniform; most tiles of a sparse field)
+#pragma unroll
+    for (int q = 0; q < NST; ++q) {   // (uniform trip count: the translation shuffles across lanes)
+        const int i = tid + q * kBlock;
+        // first vertex id of the unit, final form: region form made dense, id base added (records of an imported halo
+        // plane arrive dense, in the neighbour's numbering)
+        st_r0[q].x = dense(st_r0[q].x) + b0;
+        st_r1[q].x = xhalo ? st_r1[q].x + bhalo : dense(st_r1[q].x) + b0;
+        if (i < nstage) {
+            s_w[0][i] = st_w0[q];
+            s_w[1][i] = st_w1[q];
+            s_r[0][i] = st_r0[q];
+            s_r[1][i] = st_r1[q];
+        }
+    }
+    {
         cs = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum(cs), 63);
         if (lane == 0) s_tmp[wave] = cs;
     }
     __syncthreads();  // the only block barrier: staging done (no store is in flight yet)
+    P3D_T(t_staged);
+    P3D_TACC(0, t_begin, t_staged);
+    P3D_TACC(4, 0, 1);
     int64_t wrun = (int64_t)(s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3]) + (int64_t)a.wave_off[b * 4 + wave];
 
     // column k of unit t: (plane, index)
@@ -959,15 +1013,6 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     // the wave's cells are expanded into LDS in one round when they fit, else in eight z-octant rounds
     const u32 nc_all = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum((u32)popc64(act_all)), 63);
     const int rounds = nc_all <= (u32)kWaveCells ? 1 : 8;
-    const bool xhalo = a.halo_last && (x + 1 == d.rx - 1);  // columns 1,2 live in the imported plane
-    u32 b0 = (u32)a.vid_base, bhalo = (u32)a.halo_vid_base;
-    if (a.rank_counts) {  // uniform: a handful of scalar loads
-        int64_t acc = 0;
-        for (int r = 0; r < a.rank; ++r) acc += a.rank_counts[r];
-        b0 = (u32)acc;
-        bhalo = (u32)(acc + a.rank_counts[a.rank]);
-    }
-    const u32 bh = xhalo ? bhalo : b0;
     unsigned short* const cells = s_cells[wave];
 
     for (int rd = 0; rd < rounds; ++rd) {
@@ -983,8 +1028,11 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
             cells[off++] = (unsigned short)((tid << 6) | z);
         }
         wave_lds_sync();
+        P3D_T(t_listed);
+        P3D_TACC(1, rd == 0 ? t_staged : t_listed, t_listed);
 
         for (u32 i0 = 0; i0 < na; i0 += 64) {
+            P3D_T(t_c0);
             // phase C (lane = cell)
             const u32 i = i0 + lane;
             int mask = 0;
@@ -1002,9 +1050,7 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
                     const u64 Cx0 = W0 ^ W1, Cx3 = W3 ^ W2;   // axis-0 edges of columns (x,y) and (x,y+1)
                     const u64 Cy0 = W0 ^ W3, Cy1 = W1 ^ W2;   // axis-1 edges of columns (x,y) and (x+1,y)
                     const uint2 r0 = colr(0, t), r1 = colr(1, t), r2 = colr(2, t), r3 = colr(3, t);
-                    // (records of an imported halo plane arrive dense, in the neighbour's numbering)
-                    const u32 v0 = dense(r0.x) + b0, v1 = (xhalo ? r1.x : dense(r1.x)) + bh;
-                    const u32 v2 = (xhalo ? r2.x : dense(r2.x)) + bh, v3 = dense(r3.x) + b0;
+                    const u32 v0 = r0.x, v1 = r1.x, v2 = r2.x, v3 = r3.x;   // (made final when they were staged)
                     u32 id[12];
                     // edges at z (ranks among the bits below z)
                     id[0] = v0 + (u32)popc64(Cx0 & lowm);
@@ -1020,11 +1066,10 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
                     } else {
                         // next chunk of the same row (c+1 < ncz is implied by a valid z+1): the next staged unit
                         const uint2 n0 = colr(0, t + 1), n1 = colr(1, t + 1), n3 = colr(3, t + 1);
-                        const u32 m0 = dense(n0.x) + b0;
-                        id[4] = m0;
-                        id[6] = dense(n3.x) + b0;
-                        id[7] = m0 + (n0.y & 0xffffu);
-                        id[5] = (xhalo ? n1.x : dense(n1.x)) + bh + (n1.y & 0xffffu);
+                        id[4] = n0.x;
+                        id[6] = n3.x;
+                        id[7] = n0.x + (n0.y & 0xffffu);
+                        id[5] = n1.x + (n1.y & 0xffffu);
                     }
                     // axis-2 edges of the 4 columns (always inside this chunk)
                     const u64 S0 = (W0 >> 1) | ((u64)(nbm & 1) << 63), S1 = (W1 >> 1) | ((u64)((nbm >> 1) & 1) << 63);
@@ -1037,6 +1082,8 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
                     for (int e = 0; e < 12; ++e) s_ids[wave][e][lane] = id[e];
                 }
             }
+            P3D_T(t_c1);
+            P3D_TACC(2, t_c0, t_c1);
             // the batch's triangles, k-th triangle of every cell together: the lanes that have one write a DENSE run
             // (rank among them = position), so every store instruction covers contiguous bytes.  The three vertex ids
             // come back out of the lane's LDS column by table index (a register array cannot be indexed per lane).
@@ -1063,6 +1110,8 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
                 }
             }
             wave_lds_sync();
+            P3D_T(t_c2);
+            P3D_TACC(3, t_c1, t_c2);
         }
     }
 }
