@@ -67,6 +67,7 @@ struct Ws {  // byte offsets into the workspace
 };
 
 constexpr int kBlock = 256;
+constexpr int kPreMinChunks = 1024;   // more face chunks than this: the counting kernel also leaves their exclusive prefix
 constexpr int kHdrBytes = 8192;   // [0,256) totals/flags; [256,4352) the 32 cursors of a multi-part extraction (a whole-grid
                                   // call uses a block of the library's ring, see cursor_block_for); [4352,4608) prefixes
 // header slots (u64)
@@ -671,8 +672,8 @@ __global__ void __launch_bounds__(1024) k_stack_finish(const u64* __restrict__ c
 template <int PB>
 __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restrict__ bits, Dims d, int64_t tpp, int xw,
                                                             int cpi, u32* __restrict__ chunk_sum, u32* __restrict__ wave_off,
-                                                            u32* __restrict__ tile_tris, CompactArgs cp,
-                                                            u64* __restrict__ hdr) {
+                                                            u32* __restrict__ tile_tris, u32* __restrict__ chunk_pre,
+                                                            CompactArgs cp, u64* __restrict__ hdr) {
     if ((int)blockIdx.x < cp.nblocks) {  // the launch's first blocks move vertices (uniform per block)
         compact_block(cp, hdr, nullptr, 0);
         return;
@@ -768,7 +769,41 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
         }
         __syncthreads();
     }
-    if (tid == 0) chunk_sum[chunk] = running;
+    // With many chunks (a stack of items) the LAST chunk block to finish turns the chunk totals into their exclusive
+    // prefix (chunk_pre), so that a face tile reads one number instead of adding up to 4096 of them (with up to
+    // kPreMinChunks chunks a tile's <= 4 loads per thread ride in its single prologue round trip, and the serial tail of
+    // this scan would cost more than it saves: +6 us here vs -2 us there at 512^3).  Completion counter = the spare word
+    // next to the call's first vertex cursor (zero when the call starts: the cursor block is cleared for every call).
+    // The totals are handed over WITHOUT agent-scope fences (a release fence writes the whole L2 back: 56 us instead of
+    // 21 for this kernel): every total is stored and loaded with agent-scope (sc1) accesses, and the store is drained
+    // before the counter is bumped (MI355X_MICROARCH.md, correctness boundaries).
+    if (chunk_pre && cp.cursors) {
+        __shared__ u32 s_last, s_scan[4];
+        const u32 nchunks = gridDim.x - (u32)cp.nblocks;
+        if (tid == 0) {
+            __hip_atomic_store(chunk_sum + chunk, running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // = s_waitcnt vmcnt(0): the store has left the CU
+            const u64 prev = __hip_atomic_fetch_add((u64*)cp.cursors + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = prev == (u64)nchunks - 1ull ? 1u : 0u;
+        }
+        __syncthreads();
+        if (s_last) {
+            const u32 per = (nchunks + kBlock - 1) / kBlock;   // <= 16 (at most 4096 chunks)
+            const u32 i0 = (u32)tid * per;
+            u32 sum = 0;
+            for (u32 k = 0; k < per; ++k)
+                if (i0 + k < nchunks) sum += __hip_atomic_load(chunk_sum + i0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u32 total;
+            u32 run = block_excl_scan(sum, s_scan, &total);
+            for (u32 k = 0; k < per; ++k)
+                if (i0 + k < nchunks) {
+                    chunk_pre[i0 + k] = run;
+                    run += __hip_atomic_load(chunk_sum + i0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+        }
+    } else if (tid == 0) {
+        chunk_sum[chunk] = running;
+    }
 }
 
 // F = sum of the chunk totals -> header + host mailbox (the counting call and the slab path; the one-pass call lets
@@ -1366,7 +1401,7 @@ int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3
         StageTimer tm(ST_FACES_COUNT, st);
         const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr, 1u << 26, 1, nullptr};
         hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)w.nchunks), dim3(kBlock), 0, st, bits, d, w.tpp, w.xw, (int)w.cpi, csum,
-                           woff, (u32*)(ws + w.tile_tris), none, hdr);
+                           woff, (u32*)(ws + w.tile_tris), (u32*)nullptr, none, hdr);
     }
     {
         StageTimer tm(ST_SCAN_F, st);
@@ -1512,6 +1547,9 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     u64* bits = (u64*)(ws + w.bits);
     uint2* rec = (uint2*)(ws + w.rec);
     u32 *csum = (u32*)(ws + w.chunk_sum), *woff = (u32*)(ws + w.wave_off);
+    // exclusive prefix of the chunk totals, written by the last counting block when there are many chunks (the counting
+    // call's scan array is free here)
+    u32* cpre = w.nchunks > kPreMinChunks ? (u32*)(ws + w.bbase_v) : nullptr;
     // Vertex ids handed out by the streaming kernel are region * 2^26 + slot (a fixed stride, so they stay
     // unambiguous even when a region outgrows its share of the scratch buffer); readers make them dense on the fly.
     // Storage is store_rows rows per region; without a scratch buffer nothing is stored (pure count + ids).
@@ -1571,7 +1609,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         const CompactArgs cpe{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, early * kRegions, 0, nparts, 0,
                               csum, (int)w.nchunks, cursors, id_limit, 1, nullptr};
         hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)(w.nchunks + cpe.nblocks)), dim3(kBlock), 0, st, bits,
-                           d, w.tpp, w.xw, (int)w.cpi, csum, woff, (u32*)(ws + w.tile_tris), cpe, hdr);
+                           d, w.tpp, w.xw, (int)w.cpi, csum, woff, (u32*)(ws + w.tile_tris), cpre, cpe, hdr);
     }
     if (part == 4) {  // totals to the host now; the faces (and the rest of the vertex copy) follow in part 5
         StageTimer tm(ST_SCAN_F, st);
@@ -1581,7 +1619,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     }
     const FaceArgs a{1, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
                      slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw, (int)w.cpi,
-                     csum, nullptr, woff, (const u32*)(ws + w.tile_tris), cursors, mb, seq};
+                     csum, cpre, woff, (const u32*)(ws + w.tile_tris), cursors, mb, seq};
     const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, (nparts - early) * kRegions, early,
                          nparts, part == 5 ? 0 : 1, csum, (int)w.nchunks, cursors, id_limit, 1, nullptr};
     StageTimer tm(ST_EMIT_FACES, st);
@@ -1603,6 +1641,7 @@ int fused_stack_impl(const T* grids, const Dims& d, const Ws& w, float thresh, c
     uint2* rec = (uint2*)(ws + w.rec);
     u32 *csum = (u32*)(ws + w.chunk_sum), *woff = (u32*)(ws + w.wave_off);
     u64* cursors = (u64*)(ws + w.cur);
+    u32* cpre = w.nchunks > kPreMinChunks ? (u32*)(ws + w.bbase_v) : nullptr;   // (see fused_impl)
     HIP_TRY(hipMemsetAsync(cursors, 0, (size_t)d.nitems * kCursorBlockWords * sizeof(u64), st));
     const u32 region_rows = 1u << 26;
     const u32 id_limit = (u32)std::min<int64_t>(region_rows, std::max(1, env_int("P3D_TEST_ID_LIMIT", 1 << 26)));
@@ -1625,14 +1664,9 @@ int fused_stack_impl(const T* grids, const Dims& d, const Ws& w, float thresh, c
         const CompactArgs cpe{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, early * kRegions * d.nitems, 0,
                               nparts, 0, csum, (int)w.nchunks, cursors, id_limit, d.nitems, item_offsets};
         hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, dim3((u32)(w.nchunks + cpe.nblocks)), dim3(kBlock), 0, st, bits,
-                           d, w.tpp, w.xw, (int)w.cpi, csum, woff, (u32*)(ws + w.tile_tris), cpe, hdr);
+                           d, w.tpp, w.xw, (int)w.cpi, csum, woff, (u32*)(ws + w.tile_tris), cpre, cpe, hdr);
     }
-    // exclusive prefix of the chunk totals (the scan arrays of the counting call are free in this mode)
-    u32* cpre = (u32*)(ws + w.bbase_v);
-    const bool use_pre = w.nchunks > 1024;   // (<= 4096 chunks: the scan's padded runs fit the arrays, see make_ws)
-    if (use_pre)
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, csum, cpre, w.nchunks, hdr + H_T, nullptr, 0ull, 1);
-    const FaceArgs a{1, 0, 0, 0, nullptr, 0, w.tpp, w.xw, (int)w.cpi, csum, use_pre ? cpre : nullptr, woff,
+    const FaceArgs a{1, 0, 0, 0, nullptr, 0, w.tpp, w.xw, (int)w.cpi, csum, cpre, woff,
                      (const u32*)(ws + w.tile_tris), cursors, nullptr, 0};
     const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows,
                          (nparts - early) * kRegions * d.nitems, early, nparts, 0, csum, (int)w.nchunks, cursors, id_limit,
