@@ -476,7 +476,7 @@ struct FaceArgs {
 #define P3D_TACC(ph, a_, b_)
 #endif
 #ifndef P3D_WAVE_CELLS
-#define P3D_WAVE_CELLS 512
+#define P3D_WAVE_CELLS 256   // (2 KiB of cell lists per block: with 4 KiB the block's LDS allows 5 blocks per CU, with 2 KiB 6)
 #endif
 constexpr int kWaveCells = P3D_WAVE_CELLS;  // active cells a wave expands at a time (its 64 units have up to 4096)
 
@@ -1045,13 +1045,26 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
         return lo | (hi << 4);
     };
 
-    // the wave's cells are expanded into LDS in one round when they fit, else in eight z-octant rounds
-    const u32 nc_all = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum((u32)popc64(act_all)), 63);
-    const int rounds = nc_all <= (u32)kWaveCells ? 1 : 8;
+    // the wave's cells are expanded into LDS in one round when they fit, else in 2, 4, 8 or 16 rounds over z slices: the
+    // widest slice width (64, 32, ... voxels) whose fullest slice fits the window; 4-voxel slices always fit (64 units x 4)
+    static_assert(kWaveCells >= 256, "a 4-voxel z slice of a wave holds up to 256 cells");
+    int wbits = 64;
+    {
+        u32 fullest = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum((u32)popc64(act_all)), 63);
+        while (fullest > (u32)kWaveCells && wbits > 4) {   // (wave-uniform)
+            wbits >>= 1;
+            fullest = 0;
+            for (int sl = 0; sl < 64; sl += wbits) {
+                const u64 m = ((1ull << wbits) - 1ull) << sl;
+                fullest = max(fullest, (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum((u32)popc64(act_all & m)), 63));
+            }
+        }
+    }
+    const int rounds = 64 / wbits;
     unsigned short* const cells = s_cells[wave];
 
     for (int rd = 0; rd < rounds; ++rd) {
-        u64 act = rounds == 1 ? act_all : (act_all & (0xffull << (8 * rd)));
+        u64 act = rounds == 1 ? act_all : (act_all & (((1ull << wbits) - 1ull) << (wbits * rd)));
         // phase B
         const u32 pc = (u32)popc64(act);
         const u32 inc0 = wave_prefix_sum(pc);
