@@ -66,7 +66,7 @@ def build_capi(force: bool = False, verbose: bool = False) -> Path:
 
 def build_pybind(force: bool = False, verbose: bool = False) -> Path:
     out = pybind_path()
-    deps = [CSRC / "bindings.cpp", ROOT / "include" / "p3d_mc.h"]
+    deps = [CSRC / "bindings.cpp", ROOT / "include" / "p3d_mc.h", ROOT / "include" / "p3d_rc.h"]
     if force or _stale(out, deps):
         import torch
         from torch.utils import cpp_extension as ce
@@ -80,7 +80,7 @@ def build_pybind(force: bool = False, verbose: bool = False) -> Path:
                "-DTORCH_API_INCLUDE_EXTENSION_H", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
                *inc, str(CSRC / "bindings.cpp"), "-o", str(out),
                f"-L{tlib}", "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python", "-ltorch_hip", "-lc10_hip",
-               f"-L{PKG}", "-lp3dmc", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}", "-Wno-deprecated-declarations"]
+               f"-L{PKG}", "-lp3dmc", "-lp3drc", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}", "-Wno-deprecated-declarations"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
@@ -108,11 +108,30 @@ def build_mt(force: bool = False, verbose: bool = False) -> Path:
     return out
 
 
+def rc_path() -> Path:
+    return PKG / "libp3drc.so"
+
+
+def build_rc(force: bool = False, verbose: bool = False) -> Path:
+    """libp3drc.so: ray caster (include/p3d_rc.h): BVH4 build on the host, HIP traversal kernel."""
+    out = rc_path()
+    deps = [CSRC / "p3d_rc.hip", ROOT / "include" / "p3d_rc.h"]
+    if force or _stale(out, deps):
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
+               "-Wextra", str(CSRC / "p3d_rc.hip"), "-o", str(out)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        _write_stamp(out, deps)
+    return out
+
+
 def build_all(force: bool = False, verbose: bool = False):
     a = build_capi(force, verbose)
+    d = build_rc(force, verbose)     # (the pybind adapter links it)
     b = build_pybind(force, verbose)
     c = build_mt(force, verbose)
-    return a, b, c
+    return a, b, c, d
 
 
 if __name__ == "__main__":

@@ -5,6 +5,7 @@
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/extension.h>
+#include <hip/hip_runtime_api.h>
 
 #include <algorithm>
 #include <cstdint>
@@ -22,6 +23,7 @@
 #include <vector>
 
 #include "../../include/p3d_mc.h"
+#include "../../include/p3d_rc.h"
 
 namespace py = pybind11;
 using torch::Tensor;
@@ -231,13 +233,71 @@ void save_mesh_as_ply(const std::string filename, Tensor vertices, Tensor faces,
 
 void test() { std::cout << "hello world!" << std::endl; }  // Core/utils.cpp:10-12
 
-// Ray casting (OptiX / BVH) is outside this build's scope: the names exist so
-// that `prim3d.utility.ray_cast`'s import-time annotation resolves; using them raises.
+// Replaces the non-OptiX RayCaster of the reference (src/prim3d/Utility/ray_cast.cu:340-450): `create_raycaster`
+// builds a BVH over the mesh from HOST tensors (CHECK_CPU_INPUT, :346-347) and `invoke` writes depth, unit normal and
+// face id of the nearest hit of every ray into caller-allocated DEVICE tensors (CHECK_INPUT, :393-397).  A thin
+// adapter over the C ABI include/p3d_rc.h (libp3drc.so); same messages as the reference's macros (Core/common.h:63-71).
 struct RayCaster {
-    void invoke(py::args, py::kwargs) { throw std::runtime_error("RayCaster is not part of the MI355X marching-cubes build"); }
+    p3d_rc_caster* impl = nullptr;
+    int device = -1;
+    RayCaster() = default;
+    RayCaster(const RayCaster&) = delete;
+    RayCaster& operator=(const RayCaster&) = delete;
+    ~RayCaster() { p3d_rc_destroy(impl); }
+
+    void invoke(const Tensor& origins, const Tensor& directions, Tensor& depths, Tensor& normals, Tensor& primitives_ids) {
+        TORCH_CHECK(origins.is_cuda(), "origins must be a CUDA tensor");
+        TORCH_CHECK(origins.is_contiguous(), "origins must be contiguous");
+        TORCH_CHECK(directions.is_cuda(), "directions must be a CUDA tensor");
+        TORCH_CHECK(directions.is_contiguous(), "directions must be contiguous");
+        TORCH_CHECK(depths.is_cuda(), "depths must be a CUDA tensor");
+        TORCH_CHECK(depths.is_contiguous(), "depths must be contiguous");
+        TORCH_CHECK(normals.is_cuda(), "normals must be a CUDA tensor");
+        TORCH_CHECK(normals.is_contiguous(), "normals must be contiguous");
+        TORCH_CHECK(primitives_ids.is_cuda(), "primitives_ids must be a CUDA tensor");
+        TORCH_CHECK(primitives_ids.is_contiguous(), "primitives_ids must be contiguous");
+        // (the reference reads them with data_ptr<float>() / data_ptr<int32_t>(), :409-418: other dtypes throw)
+        for (const Tensor* t : std::initializer_list<const Tensor*>{&origins, &directions, &depths, &normals})
+            TORCH_CHECK(t->scalar_type() == torch::kFloat, "expected scalar type Float but found ", t->scalar_type());
+        TORCH_CHECK(primitives_ids.scalar_type() == torch::kInt, "expected scalar type Int but found ",
+                    primitives_ids.scalar_type());
+        const int64_t n = origins.size(0);
+        TORCH_CHECK(origins.numel() == n * 3 && directions.numel() == n * 3 && depths.numel() >= n &&
+                        normals.numel() >= n * 3 && primitives_ids.numel() >= n,
+                    "ray tensors must hold num_rays entries (origins / directions / normals x3)");
+        TORCH_CHECK(origins.device().index() == device, "the ray caster lives on cuda:", device);
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(origins.device());
+        void* stream = (void*)c10::hip::getCurrentHIPStream(origins.device().index()).stream();
+        const int rc = p3d_rc_invoke(impl, origins.data_ptr<float>(), directions.data_ptr<float>(), n,
+                                     depths.data_ptr<float>(), normals.data_ptr<float>(),
+                                     primitives_ids.data_ptr<int32_t>(), stream);
+        TORCH_CHECK(rc == P3D_RC_OK, "p3d_rc_invoke failed (", rc, "): ", p3d_rc_last_error());
+    }
 };
-py::object create_raycaster(py::args, py::kwargs) {
-    throw std::runtime_error("create_raycaster is not part of the MI355X marching-cubes build");
+
+RayCaster* create_raycaster(const Tensor& vertices, const Tensor& faces) {
+    TORCH_CHECK(!vertices.is_cuda(), "vertices must be a CPU tensor");
+    TORCH_CHECK(vertices.is_contiguous(), "vertices must be contiguous");
+    TORCH_CHECK(!faces.is_cuda(), "faces must be a CPU tensor");
+    TORCH_CHECK(faces.is_contiguous(), "faces must be contiguous");
+    TORCH_CHECK(vertices.scalar_type() == torch::kFloat, "expected scalar type Float but found ", vertices.scalar_type());
+    TORCH_CHECK(faces.scalar_type() == torch::kInt, "expected scalar type Int but found ", faces.scalar_type());
+    TORCH_CHECK(vertices.dim() == 2 && vertices.size(1) == 3 && faces.dim() == 2 && faces.size(1) == 3,
+                "expected vertices [V,3] and faces [F,3]");
+    auto* rc = new RayCaster();
+    const int code = p3d_rc_create(vertices.data_ptr<float>(), vertices.size(0), faces.data_ptr<int32_t>(), faces.size(0),
+                                   &rc->impl);
+    if (code != P3D_RC_OK) {
+        delete rc;
+        TORCH_CHECK(false, "p3d_rc_create failed (", code, "): ", p3d_rc_last_error());
+    }
+    int64_t nn = 0, nt = 0;
+    int32_t depth = 0;
+    (void)p3d_rc_stats(rc->impl, &nn, &nt, &depth);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    rc->device = dev;
+    return rc;
 }
 
 }  // namespace
@@ -247,7 +307,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.attr("enable_optix") = false;
     m.def("test", &test);
     py::class_<RayCaster>(m, "RayCaster").def("invoke", &RayCaster::invoke);
-    m.def("create_raycaster", &create_raycaster);
+    m.def("create_raycaster", &create_raycaster, py::return_value_policy::take_ownership);
     m.def("marching_cubes", &marching_cubes);
     m.def("save_mesh_as_ply", &save_mesh_as_ply);
 }

@@ -40,6 +40,20 @@ def test_tetrahedra_header_functions_are_exported(built):
     assert tetrahedra.lib().p3d_mt_workspace_bytes(1 << 33, 4, ctypes.byref(nbytes)) < 0
 
 
+def test_raycaster_header_functions_are_exported(built):
+    """include/p3d_rc.h <-> libp3drc.so (the pybind adapter links it; no compute calls without a GPU)."""
+    from primitive3d_amd._build import rc_path
+    lib = ctypes.CDLL(str(rc_path()))
+    names = declared_functions("p3d_rc.h")
+    assert names == sorted(["p3d_rc_abi_version", "p3d_rc_create", "p3d_rc_destroy", "p3d_rc_invoke", "p3d_rc_last_error",
+                            "p3d_rc_stats"])
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/p3d_rc.h but not exported"
+    lib.p3d_rc_abi_version.restype = ctypes.c_int
+    assert lib.p3d_rc_abi_version() == 1
+    assert hasattr(built.libPrim3D, "create_raycaster") and hasattr(built.libPrim3D.RayCaster, "invoke")
+
+
 def test_host_only_entry_points(built):
     from primitive3d_amd import capi
     assert capi.lib().p3d_mc_abi_version() == 5

@@ -1,0 +1,105 @@
+"""GPU parity of the BVH ray caster (libp3drc.so through the reference-shaped `create_raycaster` / `RayCaster.invoke`)
+against the brute-force restatement of the reference's result (oracle/rc_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.rc_oracle import MAX_DIST, raycast_oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5   # depths are asserted bit-identical where the winner is unambiguous; TOL bounds everything else
+
+
+def _cast(built, gpu, v, f, ro, rd):
+    rc = built.create_raycaster(torch.from_numpy(v), torch.from_numpy(f))
+    n = ro.shape[0]
+    depths = torch.empty(n, device=gpu)
+    normals = torch.empty((n, 3), device=gpu)
+    ids = torch.empty(n, dtype=torch.int32, device=gpu)
+    rc.invoke(torch.from_numpy(ro).to(gpu), torch.from_numpy(rd).to(gpu), depths, normals, ids)
+    torch.cuda.synchronize()
+    return depths.cpu().numpy(), normals.cpu().numpy(), ids.cpu().numpy()
+
+
+def _compare(got, ref):
+    d, n, i = got
+    rd_, rn, ri, second = ref
+    assert np.array_equal(i >= 0, ri >= 0), "hit / miss pattern differs"
+    assert np.abs(d.astype(np.float64) - rd_).max() <= TOL
+    clear = (ri >= 0) & ((second - rd_) > 1e-4)       # the runner-up is well behind: the winner is unambiguous
+    assert clear.sum() >= 0.5 * (ri >= 0).sum()
+    assert np.array_equal(i[clear], ri[clear]), "face ids differ on unambiguous hits"
+    assert np.array_equal(d[clear], rd_[clear]), "depths differ in the last bits on unambiguous hits"
+    assert np.abs(n[clear] - rn[clear]).max() <= TOL
+    miss = ri < 0
+    assert np.all(d[miss] == MAX_DIST) and np.all(n[miss] == 0) and np.all(i[miss] == -1)
+
+
+def _rays(rng, n, scale=1.0):
+    ro = (rng.standard_normal((n, 3)) * 2.5 * scale).astype(np.float32)
+    tgt = (rng.standard_normal((n, 3)) * 0.6 * scale).astype(np.float32)
+    rd = tgt - ro
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    return ro, rd.astype(np.float32)
+
+
+@pytest.mark.parametrize("ntri", [1, 7, 9, 300, 20000])
+def test_random_triangle_soup(gpu, built, ntri):
+    rng = np.random.default_rng(ntri)
+    c = rng.uniform(-1, 1, (ntri, 1, 3))
+    v = (c + rng.normal(0, 0.15, (ntri, 3, 3))).reshape(-1, 3).astype(np.float32)
+    f = np.arange(ntri * 3, dtype=np.int32).reshape(ntri, 3)
+    ro, rd = _rays(rng, 3000)
+    # half of the rays aim at a triangle's centroid (so that even a single triangle is hit), half at random points
+    cen = v.reshape(ntri, 3, 3).mean(1)[rng.integers(0, ntri, 1500)]
+    rd[:1500] = cen - ro[:1500]
+    rd[:1500] /= np.linalg.norm(rd[:1500], axis=1, keepdims=True)
+    ref = raycast_oracle(v, f, ro, rd)
+    assert (ref[2] >= 0).sum() > 500
+    _compare(_cast(built, gpu, v, f, ro, rd), ref)
+
+
+def test_marching_cubes_mesh_and_axis_aligned_rays(gpu, built):
+    """The natural consumer of (vertices, faces): rays onto an extracted sphere, including rays with zero direction
+    components (the slab test's 0 * inf cases) and rays that start inside the mesh."""
+    from primitive3d_amd.fields import sphere_grid
+    v, f = built.marching_cubes(sphere_grid(64), 0, scale=2.0)     # sphere of radius 0.25 around (0.5, 0.5, 0.5)
+    v, f = v.cpu().numpy(), f.cpu().numpy()
+    rng = np.random.default_rng(5)
+    ro, rd = _rays(rng, 2000, scale=0.2)
+    ro += 0.5
+    g = np.linspace(0.3, 0.7, 24, dtype=np.float32)
+    gx, gy = np.meshgrid(g, g, indexing="ij")
+    ax_o = np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, -1.0, np.float32)], 1)
+    ax_d = np.tile(np.array([[0, 0, 1]], np.float32), (gx.size, 1))
+    inside_o = np.tile(np.array([[0.5, 0.5, 0.5]], np.float32), (64, 1))
+    inside_d = rng.standard_normal((64, 3)).astype(np.float32)
+    inside_d /= np.linalg.norm(inside_d, axis=1, keepdims=True)
+    ro = np.concatenate([ro, ax_o, inside_o]).astype(np.float32)
+    rd = np.concatenate([rd, ax_d, inside_d]).astype(np.float32)
+    got = _cast(built, gpu, v, f, ro, rd)
+    _compare(got, raycast_oracle(v, f, ro, rd))
+    hit = got[2] >= 0
+    assert hit[-64:].all() and np.abs(got[0][-64:] - 0.25).max() < 0.02   # from the centre: the radius, every time
+
+
+def test_far_hits_are_misses_and_errors(gpu, built):
+    """MAX_DIST = 10 (bvh.cu:13): a triangle 12 units away is not hit; wrong devices / dtypes raise like the
+    reference's CHECK_* macros."""
+    v = np.array([[-1, -1, 12], [1, -1, 12], [0, 1, 12], [-1, -1, 3], [1, -1, 3], [0, 1, 3]], np.float32)
+    ro = np.zeros((2, 3), np.float32)
+    rd = np.array([[0, 0, 1], [0, 0, 1]], np.float32)
+    d, n, i = _cast(built, gpu, v[:3], np.array([[0, 1, 2]], np.int32), ro, rd)
+    assert np.all(d == 10.0) and np.all(i == -1)
+    d, n, i = _cast(built, gpu, v, np.array([[0, 1, 2], [3, 4, 5]], np.int32), ro, rd)
+    assert np.all(d == 3.0) and np.all(i == 1) and np.allclose(np.abs(n), [[0, 0, 1]] * 2)
+    C = built.libPrim3D
+    with pytest.raises(RuntimeError, match="must be a CPU tensor"):
+        C.create_raycaster(torch.from_numpy(v).to(gpu), torch.tensor([[0, 1, 2]], dtype=torch.int32))
+    with pytest.raises(RuntimeError, match="expected scalar type Int"):
+        C.create_raycaster(torch.from_numpy(v), torch.tensor([[0, 1, 2]]))
+    rc = built.create_raycaster(torch.from_numpy(v).to(gpu), torch.tensor([[0, 1, 2]], dtype=torch.int32).to(gpu))
+    o = torch.zeros(2, 3)
+    with pytest.raises(RuntimeError, match="origins must be a CUDA tensor"):
+        rc.invoke(o, o.to(gpu), torch.empty(2, device=gpu), torch.empty(2, 3, device=gpu),
+                  torch.empty(2, dtype=torch.int32, device=gpu))
