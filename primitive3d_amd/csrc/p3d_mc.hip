@@ -465,16 +465,6 @@ struct FaceArgs {
     u64 seq;
 };
 
-// dev-only: -DP3D_FACES_TIMING accumulates per-phase shader cycles of k_faces (one atomic per wave and phase) into
-// hdr[600 + phase]: 0 prologue up to the barrier, 1 per-unit work + cell list, 2 cell phase (ids), 3 triangle rounds,
-// 4 waves counted
-#ifdef P3D_FACES_TIMING
-#define P3D_T(var) const u64 var = __builtin_readcyclecounter()
-#define P3D_TACC(ph, a_, b_) do { if ((threadIdx.x & 63) == 0) atomicAdd(hdr + 600 + (ph), (u64)((b_) - (a_))); } while (0)
-#else
-#define P3D_T(var)
-#define P3D_TACC(ph, a_, b_)
-#endif
 #ifndef P3D_WAVE_CELLS
 #define P3D_WAVE_CELLS 256   // (2 KiB of cell lists per block: with 4 KiB the block's LDS allows 5 blocks per CU, with 2 KiB 6)
 #endif
@@ -901,8 +891,6 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     __shared__ unsigned short s_cells[4][kWaveCells];    // per wave: active cells of the round, unit-in-tile << 6 | z
     __shared__ u32 s_ids[4][12][64];                     // per wave: vertex ids of the batch's cells' 12 edges
     __shared__ u32 s_tmp[4];
-
-    P3D_T(t_begin);
     const bool XLATE = a.xlate == 1 || (a.xlate == 2 && hdr[H_RECFORM] != 0ull);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     s_tab[tid] = g_tri_packed[tid];
@@ -952,7 +940,7 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     // A cell's four columns W00,W10,W11,W01 are then plane 0/1 at index t and t + hoff.
     // ALL global loads of the prologue are issued before any of them is waited for -- the tile's triangle count, the
     // region cursors (above), the staged words and records, this thread's share of the chunk totals: one memory round
-    // trip instead of three dependent ones (measured with -DP3D_FACES_TIMING: the prologue was 58 % of a wave's life).
+    // trip instead of three dependent ones (-5 us at 512^3).
     const bool one_range = d.ncz <= NHALO;
     const int hoff = one_range ? d.ncz : kBlock + 1;   // index distance of the y+1 column
     const int nstage = one_range ? kBlock + d.ncz + 1 : 2 * (kBlock + 1);
@@ -1005,9 +993,9 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
         if (lane == 0) s_tmp[wave] = cs;
     }
     __syncthreads();  // the only block barrier: staging done (no store is in flight yet)
-    P3D_T(t_staged);
-    P3D_TACC(0, t_begin, t_staged);
-    P3D_TACC(4, 0, 1);
+#ifdef P3D_FACES_ABL   // dev-only: 1 = prologue only (wrong results)
+    if (P3D_FACES_ABL == 1) return;
+#endif
     int64_t wrun = (int64_t)(s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3]) + (int64_t)a.wave_off[b * 4 + wave];
 
     // column k of unit t: (plane, index)
@@ -1076,11 +1064,8 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
             cells[off++] = (unsigned short)((tid << 6) | z);
         }
         wave_lds_sync();
-        P3D_T(t_listed);
-        P3D_TACC(1, rd == 0 ? t_staged : t_listed, t_listed);
 
         for (u32 i0 = 0; i0 < na; i0 += 64) {
-            P3D_T(t_c0);
             // phase C (lane = cell)
             const u32 i = i0 + lane;
             int mask = 0;
@@ -1130,8 +1115,6 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
                     for (int e = 0; e < 12; ++e) s_ids[wave][e][lane] = id[e];
                 }
             }
-            P3D_T(t_c1);
-            P3D_TACC(2, t_c0, t_c1);
             // the batch's triangles, k-th triangle of every cell together: the lanes that have one write a DENSE run
             // (rank among them = position), so every store instruction covers contiguous bytes.  The three vertex ids
             // come back out of the lane's LDS column by table index (a register array cannot be indexed per lane).
@@ -1158,8 +1141,6 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
                 }
             }
             wave_lds_sync();
-            P3D_T(t_c2);
-            P3D_TACC(3, t_c1, t_c2);
         }
     }
 }
