@@ -74,6 +74,20 @@ def test_c3_perlin_512_full_size(gpu, built):
     assert torch.equal(a, b)
 
 
+def test_c3_whole_mesh_equals_the_oracle(gpu, built):
+    """The headline workload at its full size: the WHOLE 512^3 mesh (positions bit for bit, winding kept) against the CPU
+    oracle run on all host cores -- not only counts and properties."""
+    from primitive3d_amd.fields import perlin_grid
+    from oracle import oracle_extract
+    g = perlin_grid(512, period=64, seed=0, device=gpu)
+    v, f = built.marching_cubes(g, 0.0)
+    rv, rf, _ = oracle_extract(g.cpu().numpy(), 0.0, threads=0, want_keys=False)
+    assert v.shape[0] == rv.shape[0] and f.shape[0] == rf.shape[0]
+    assert torch.equal(soup_hashes(v, f), soup_hashes(torch.from_numpy(rv).to(gpu), torch.from_numpy(rf).to(gpu)))
+    a = np.sort(v.cpu().numpy().view([("", np.float32)] * 3), axis=0)
+    assert np.array_equal(a, np.sort(rv.view([("", np.float32)] * 3), axis=0))
+
+
 def test_c2_bunny_resampled_256(gpu, built):
     """bunny.npy (66^3) trilinearly resampled to 256^3 as SURVEY.md section 8d defines C2; native 66^3 counts too."""
     from pathlib import Path
@@ -84,6 +98,9 @@ def test_c2_bunny_resampled_256(gpu, built):
     v, f = built.marching_cubes(big.to(gpu), 0.0)
     assert (v.shape[0], f.shape[0]) == oracle_count(big.numpy(), 0.0) == torch_counts(big.to(gpu), 0.0)
     mesh_properties(v, f)
+    from oracle import oracle_extract
+    rv, rf, _ = oracle_extract(big.numpy(), 0.0, threads=0, want_keys=False)   # the whole 256^3 mesh, bit for bit
+    assert torch.equal(soup_hashes(v, f), soup_hashes(torch.from_numpy(rv).to(gpu), torch.from_numpy(rf).to(gpu)))
     # the bunny SDF is closed inside the grid: Euler characteristic 2
     e = torch.cat([f.long()[:, [0, 1]], f.long()[:, [1, 2]], f.long()[:, [2, 0]]]).sort(dim=1).values
     n_e = (e[:, 0] * v.shape[0] + e[:, 1]).unique().numel()
