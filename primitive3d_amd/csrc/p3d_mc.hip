@@ -893,8 +893,16 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     __shared__ u32 s_tmp[4];
     const bool XLATE = a.xlate == 1 || (a.xlate == 2 && hdr[H_RECFORM] != 0ull);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    s_tab[tid] = g_tri_packed[tid];
-    s_ntri[tid] = g_tri_count[tid];
+    // the case tables are indexed by the INTERLEAVED corner mask (bit 2k = column k at z, bit 2k+1 = column k at z+1:
+    // what one shift per column yields); the reference's mask (marching_cubes.cu:49-57: bits 0-3 at z, 4-7 at z+1) is
+    // this fixed permutation of it
+    {
+        int m = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m |= (((tid >> (2 * k)) & 1) << k) | (((tid >> (2 * k + 1)) & 1) << (k + 4));
+        s_tab[tid] = g_tri_packed[m];
+        s_ntri[tid] = g_tri_count[m];
+    }
     // dense base of every vertex region = exclusive prefix over the region cursors, kept by EVERY wave in a register
     // (lane r = base of region r): the records are translated once, when they are staged, not once per cell
     u32 pref = 0;
@@ -1011,7 +1019,7 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
             const u64 Wk = valid ? colw(k, tid) : 0ull;
             const u64 nb = (valid && more) ? (colw(k, tid + 1) & 1ull) : 0ull;
             const u64 S = (Wk >> 1) | (nb << 63);
-            nbits |= (int)nb << k;
+            nbits |= (int)nb << (2 * k + 1);
             orr |= Wk | S;
             andd &= Wk & S;
         }
@@ -1020,17 +1028,13 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     }
     wave_lds_sync();  // s_nb of this wave's units is read by this wave's cell lanes
 
-    // corner mask of a cell: bits 0-3 = columns at z, bits 4-7 = the same columns at z+1
+    // interleaved corner mask of a cell: one 64-bit shift per column yields its bits at z and z+1; the z+1 corners of a
+    // chunk's last voxel live in the next chunk (s_nb, stored in the same interleaved positions)
     auto cell_mask = [&](int t, int z) {
-        int lo = 0, hi = 0;
-        const int nbm = s_nb[t];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const u64 Wk = colw(k, t);
-            lo |= (int)((Wk >> z) & 1ull) << k;
-            hi |= (z < 63 ? (int)((Wk >> (z + 1)) & 1ull) : ((nbm >> k) & 1)) << k;
-        }
-        return lo | (hi << 4);
+        const u32 t0 = (u32)(colw(0, t) >> z), t1 = (u32)(colw(1, t) >> z);
+        const u32 t2 = (u32)(colw(2, t) >> z), t3 = (u32)(colw(3, t) >> z);
+        const u32 m = (t0 & 3u) | ((t1 & 3u) << 2) | ((t2 & 3u) << 4) | ((t3 & 3u) << 6);
+        return (int)(m | (z == 63 ? (u32)s_nb[t] : 0u));
     };
 
     // the wave's cells are expanded into LDS in one round when they fit, else in 2, 4, 8 or 16 rounds over z slices: the
@@ -1078,7 +1082,6 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
                 if (nt) {
                     // crossing words of the 4 columns within this chunk
                     const u64 W0 = colw(0, t), W1 = colw(1, t), W2 = colw(2, t), W3 = colw(3, t);
-                    const int nbm = s_nb[t];
                     const u64 lowm = below(z);
                     const u64 Cx0 = W0 ^ W1, Cx3 = W3 ^ W2;   // axis-0 edges of columns (x,y) and (x,y+1)
                     const u64 Cy0 = W0 ^ W3, Cy1 = W1 ^ W2;   // axis-1 edges of columns (x,y) and (x+1,y)
@@ -1104,13 +1107,12 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
                         id[7] = n0.x + (n0.y & 0xffffu);
                         id[5] = n1.x + (n1.y & 0xffffu);
                     }
-                    // axis-2 edges of the 4 columns (always inside this chunk)
-                    const u64 S0 = (W0 >> 1) | ((u64)(nbm & 1) << 63), S1 = (W1 >> 1) | ((u64)((nbm >> 1) & 1) << 63);
-                    const u64 S2 = (W2 >> 1) | ((u64)((nbm >> 2) & 1) << 63), S3 = (W3 >> 1) | ((u64)((nbm >> 3) & 1) << 63);
-                    id[8] = v0 + (r0.y >> 16) + (u32)popc64((W0 ^ S0) & lowm);
-                    id[9] = v1 + (r1.y >> 16) + (u32)popc64((W1 ^ S1) & lowm);
-                    id[10] = v2 + (r2.y >> 16) + (u32)popc64((W2 ^ S2) & lowm);
-                    id[11] = v3 + (r3.y >> 16) + (u32)popc64((W3 ^ S3) & lowm);
+                    // axis-2 edges of the 4 columns (always inside this chunk): crossing word = W ^ (W >> 1); the bit the
+                    // next chunk would shift in lands at position 63, which below(z) never includes
+                    id[8] = v0 + (r0.y >> 16) + (u32)popc64((W0 ^ (W0 >> 1)) & lowm);
+                    id[9] = v1 + (r1.y >> 16) + (u32)popc64((W1 ^ (W1 >> 1)) & lowm);
+                    id[10] = v2 + (r2.y >> 16) + (u32)popc64((W2 ^ (W2 >> 1)) & lowm);
+                    id[11] = v3 + (r3.y >> 16) + (u32)popc64((W3 ^ (W3 >> 1)) & lowm);
 #pragma unroll
                     for (int e = 0; e < 12; ++e) s_ids[wave][e][lane] = id[e];
                 }
