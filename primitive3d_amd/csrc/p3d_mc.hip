@@ -1004,7 +1004,9 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
 #ifdef P3D_FACES_ABL   // dev-only: 1 = prologue only (wrong results)
     if (P3D_FACES_ABL == 1) return;
 #endif
-    int64_t wrun = (int64_t)(s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3]) + (int64_t)a.wave_off[b * 4 + wave];
+    // first face of this wave (face indices fit 32 bits: F <= int32, p3d_mc_read_counts) and the capacity as u32
+    u32 wrun = (s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3]) + a.wave_off[b * 4 + wave];
+    const u32 cap32 = (u32)min(cap_faces, (int64_t)0x7fffffff);
 
     // column k of unit t: (plane, index)
     auto colw = [&](int k, int t) -> u64 { return s_w[(k == 1 || k == 2) ? 1 : 0][t + (k >= 2 ? hoff : 0)]; };
@@ -1125,10 +1127,10 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
                 for (u32 k = 0; k < 5; ++k) {
                     const u64 have = __ballot(k < nt);
                     if (!have) break;  // wave-uniform
-                    const int64_t f = wrun + mbcnt64(have);
-                    if (k < nt && f < cap_faces) {
+                    const u32 f = wrun + mbcnt64(have);
+                    if (k < nt && f < cap32) {
                         const u32 row3 = (u32)(row >> (12 * k));
-                        int32_t* o3 = faces + f * 3;
+                        int32_t* o3 = faces + (size_t)f * 3;
                         // one 12-byte streaming store: the faces are never read again by this call, and keeping them
                         // out of the caches lets the next call's streaming kernel start clean (-8 us on k_fused in a
                         // back-to-back call stream; with the dense runs the stores fill whole sectors)
@@ -1139,7 +1141,7 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
                         tv.z = (int32_t)s_ids[wave][(row3 >> 8) & 15u][lane];
                         __builtin_nontemporal_store(tv, (i3u*)o3);
                     }
-                    wrun += popc64(have);
+                    wrun += (u32)popc64(have);
                 }
             }
             wave_lds_sync();
