@@ -1460,8 +1460,10 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
     // planes per block: enough blocks to fill the chip a few times over, but >= 8 planes (x-halo overhead 1/XT)
     // unless the grid is so small that 8-plane blocks would leave most CUs idle (then latency wins over the halo)
     const int64_t per_slab = (int64_t)g.nzt * g.nyt * (stack ? d.nitems : 1);
-    int64_t want_slabs = (env_int("P3D_FUSED_BLOCKS", 4096) + per_slab - 1) / per_slab;
-    int xt = (int)((nplanes + want_slabs - 1) / want_slabs);
+    // (measured, tools/dev/xt_sweep*.sh / blocks_sweep.sh: about 2000 blocks and at most 16 planes per block -- 12 planes
+    //  at 512^3 (120 us vs 124 with 8), 16 at 1024^3 (976 us vs 1140 with the 43 an uncapped rule gave))
+    int64_t want_slabs = (env_int("P3D_FUSED_BLOCKS", 2048) + per_slab - 1) / per_slab;
+    int xt = (int)std::min<int64_t>(16, (nplanes + want_slabs - 1) / want_slabs);
     if (xt < 8) {
         const int64_t blocks_at_8 = per_slab * ((nplanes + 7) / 8);
         if (blocks_at_8 >= 1024) xt = 8;
