@@ -685,7 +685,7 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
     const bool valid = (p < d.P) && (y + 1 < d.ry);
     const bool more = c + 1 < d.ncz;
     const u64 cells = valid ? zedge(d, c) : 0ull;
-    u32 running = 0;  // threads 0..3: triangles of the chunk before this wave's share of the current plane
+    u32 running = 0;  // first wave: triangles of the chunk before the current sub-batch
     for (int64_t xs = x_begin; xs < x_end; xs += PB) {
         u64 Wp[PB + 1], Wq[PB + 1];  // columns (x', y) and (x', y+1) of this unit for x' = xs .. xs+PB
         u32 first = 0, nbs = 0;
@@ -748,15 +748,22 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
             if (lane == 0) s_part[i][wave] = n;
         });
         __syncthreads();
-        if (tid < 4) {  // thread w keeps the running offset of wave w
-            for (int i = 0; i < PB && xs + i < x_end; ++i) {
-                u32 mine = running;
-                for (int w = 0; w < tid; ++w) mine += s_part[i][w];
-                wave_off[((xs + i) * tpp + tile) * 4 + tid] = mine;
-                const u32 all4 = s_part[i][0] + s_part[i][1] + s_part[i][2] + s_part[i][3];
-                if (tid == 0) tile_tris[(xs + i) * tpp + tile] = all4;
-                running += all4;
+        // offsets of the sub-batch in one scan by the first wave: lane l = (plane i = l / 4, wave w = l % 4), so the
+        // exclusive prefix over the lanes is "triangles of the chunk before wave w of plane i" (every lane keeps `running`)
+        if (tid < 64) {
+            const int i = lane >> 2, w = lane & 3;
+            const bool live = i < PB && xs + i < x_end;
+            const u32 val = live ? s_part[i < PB ? i : 0][w] : 0u;
+            const u32 inc = wave_prefix_sum(val);
+            if (live) {
+                wave_off[((xs + i) * tpp + tile) * 4 + w] = running + inc - val;
+                // (lane i*4+3 holds the inclusive prefix at the end of plane i; the plane's total = that minus the
+                //  exclusive prefix at its first lane)
+                const u32 at_end = (u32)__builtin_amdgcn_ds_bpermute((lane | 3) << 2, (int)inc);
+                const u32 at_begin = (u32)__builtin_amdgcn_ds_bpermute((lane & ~3) << 2, (int)(inc - val));
+                if (w == 0) tile_tris[(xs + i) * tpp + tile] = at_end - at_begin;
             }
+            running += (u32)__builtin_amdgcn_readlane((int)inc, 63);
         }
         __syncthreads();
     }
