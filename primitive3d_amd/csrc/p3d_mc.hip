@@ -868,7 +868,7 @@ __global__ void __launch_bounds__(kBlock) k_export_plane_records(const uint2* __
 // four waves never meet again: wave w owns the cells of units 64w .. 64w+63 and knows where its faces start
 // (wave_off from k_face_count_walk + the chunk totals before its chunk).
 //   phase A (lane = unit, block) : the 2x2 column words, their next-chunk bits, vertex-id records -> LDS
-//   phase B (lane = unit, wave)  : dense list of the wave's active cells (8 z-octant rounds if it does not fit)
+//   phase B (lane = unit, wave)  : dense list of the wave's active cells (2 .. 16 rounds over z slices if it does not fit)
 //   phase C (lane = cell, wave)  : corner mask, the cell's 12 edge vertex ids -> the lane's column of the wave's LDS
 //                                  slice, then the k-th triangles of all cells together (k < 5): three ids read back
 //                                  by table index, one 12-byte streaming store per lane, the lanes that have a k-th
@@ -878,8 +878,8 @@ __global__ void __launch_bounds__(kBlock) k_export_plane_records(const uint2* __
 // s_waitcnt vmcnt would wait for the stores in flight too).  With a.xlate the records are read in the streaming
 // kernel's region form (region * 2^26 + slot) and made dense on the fly from the 32 region cursors, so no pass over
 // the records has to precede the faces.
-// NHALO: units staged beyond the tile's 256 for the y+1 columns -- 32 (rows of at most 32 chunks, rz <= 2048: 31.6 KiB
-// of LDS, five tiles per CU) or 256 (any row length: four tiles per CU).
+// NHALO: units staged beyond the tile's 256 for the y+1 columns -- 32 (rows of at most 32 chunks, rz <= 2048: 26.7 KiB
+// of LDS, six tiles per CU) or 256 (any row length: fewer tiles per CU).
 template <int NHALO>
 __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, const uint2* __restrict__ rec, Dims d,
                                                   FaceArgs a, CompactArgs cp, u64* __restrict__ hdr,
