@@ -250,3 +250,34 @@ def test_ply_of_a_device_resident_extraction(gpu, built, tmp_path):
     colors = (torch.rand(v.shape, device=gpu) * 255).to(torch.uint8)
     built.libPrim3D.save_mesh_as_ply(str(p), v, f, colors)
     assert p.read_bytes() == reference_ply_bytes(vn, fn, colors.cpu().numpy())
+
+
+@pytest.mark.parametrize("env", [{"P3D_MC_MODE": "exact"}, {"P3D_MC_EXACT_ALLOC": "1"}, {}])
+def test_adapter_modes_in_a_fresh_process(gpu, env):
+    """The pybind adapter's two switches are read once per process: `P3D_MC_MODE=exact` (count pass, then an exactly
+    sized pass, the reference's own structure) and `P3D_MC_EXACT_ALLOC=1` (returned tensors always own exactly V / F
+    rows).  Each must give the oracle's counts on repeated calls; with exact allocations the storage sizes are exact."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    code = ("import sys, torch; sys.path.insert(0, %r)\n"
+            "import primitive3d_amd as p3d\n"
+            "from tests.cases import small_cases\n"
+            "g, t, lo, up = small_cases()['noise_33x17x200']\n"
+            "x = torch.from_numpy(g).cuda()\n"
+            "for _ in range(3):\n"
+            "    v, f = p3d.libPrim3D.marching_cubes(x, t, lo, up)\n"
+            "torch.cuda.synchronize()\n"
+            "print(v.shape[0], f.shape[0], v.untyped_storage().nbytes() // 12, f.untyped_storage().nbytes() // 12)\n") % str(root)
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    g, t, _, _ = small_cases()["noise_33x17x200"]
+    nv, nf = oracle_count(g, t)
+    got = [int(s) for s in out.stdout.split()]
+    assert got[:2] == [nv, nf]
+    if env:   # exact allocations: the storage holds exactly the rows
+        assert got[2:] == [nv, nf], got
+    else:     # default: rows [0, V) of a buffer that may be up to 1/8 + 4096 rows longer
+        assert nv <= got[2] <= nv + nv // 8 + 4096 and nf <= got[3] <= nf + nf // 8 + 4096, got
