@@ -142,6 +142,25 @@ def test_ply_writer_rejects_other_dtypes_like_the_reference(built, tmp_path):
         built.save_mesh(v, f, filename="mesh.obj")
 
 
+def test_reference_module_paths_resolve(built):
+    """Callers that import the reference's sub-modules directly (prim3d.utility.*, prim3d.misc.*, prim3d.version) keep
+    working against the alias package."""
+    import prim3d
+    from prim3d.misc import Timer
+    from prim3d.misc.utils import TimerError, scale_to_bound
+    from prim3d.utility import create_raycaster, marching_cubes, marching_tetrahedras, save_mesh
+    from prim3d.utility.marching_cubes import marching_cubes as mc2
+    from prim3d.utility.marching_tetrahedras import marching_tetrahedras as mt2
+    from prim3d.utility.ray_cast import create_raycaster as rc2
+    from prim3d.version import __version__
+    assert marching_cubes is prim3d.marching_cubes is mc2 and save_mesh is prim3d.save_mesh
+    assert marching_tetrahedras is prim3d.marching_tetrahedras is mt2 and create_raycaster is prim3d.create_raycaster is rc2
+    assert Timer is prim3d.Timer and issubclass(TimerError, Exception) and __version__ == prim3d.__version__
+    assert scale_to_bound(2.0) == ([0.0, 0.0, 0.0], [2.0, 2.0, 2.0])
+    assert set(prim3d.__all__) == {"__version__", "ENABLE_OPTIX", "Timer", "create_raycaster", "marching_cubes", "save_mesh",
+                                   "marching_tetrahedras"}   # prim3d/__init__.py:12-16 of the reference
+
+
 def test_package_surface(built):
     import prim3d
     assert prim3d.ENABLE_OPTIX is False and prim3d.__version__
