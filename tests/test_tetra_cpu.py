@@ -23,3 +23,16 @@ def test_oracle_reproduces_reference_outputs(path):
 def test_goldens_cover_the_reference_example():
     g = np.load(Path(__file__).parent / "golden" / "tetra_example_sphere.npz")
     assert g["points"].shape == (2056, 3) and g["tets"].shape == (12045, 4) and g["verts"].shape[0] == 4650
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[p.stem for p in GOLD])
+def test_tensor_op_baseline_reproduces_reference_outputs(path):
+    """oracle/mt_torch.py (the op chain tools/bench_next.py times beside the HIP library) is pinned the same way."""
+    import torch
+    from oracle.mt_torch import mt_torch
+    g = np.load(path)
+    tets = torch.from_numpy(g["tets"].copy())
+    v, f, ti = mt_torch(torch.from_numpy(g["points"]), tets, torch.from_numpy(g["sdf"]), True)
+    assert np.array_equal(tets.numpy(), g["tets_after"])
+    assert np.array_equal(f.numpy(), g["faces"]) and np.array_equal(ti.numpy(), g["tet_idx"])
+    assert np.array_equal(v.numpy(), g["verts"])
