@@ -3,7 +3,8 @@
  *
  * Replaces the tensor-op chain of the reference's prim3d/utility/marching_tetrahedras.py:89-235 (a kaolin-derived,
  * pure-PyTorch function: ~25 small kernels, two boolean-mask compactions, a row-wise torch.unique over all edges of the
- * active tetrahedra) by five hand-written HIP kernels around one radix sort of 64-bit edge keys.  Same results:
+ * active tetrahedra) by a handful of hand-written HIP kernels around a hash set of the CROSSING edges and one radix sort
+ * of the distinct ones (only those become vertices).  Same results:
  *   - the orientation fix of :147-148 (tets with a negative [1,x,y,z] determinant get corners 0 and 1 swapped, IN
  *     PLACE in the caller's array, as the reference does),
  *   - vertices in the order of torch.unique's sorted rows (:160-171), computed with the reference's float32 operation
@@ -32,7 +33,7 @@ extern "C" {
 #define P3D_MT_ERANGE (-2)   /* more than 2^32 - 1 vertices, or more edges than 32-bit slots */
 #define P3D_MT_EHIP (-3)
 
-/* Device scratch for a mesh of num_tets tetrahedra (worst case: every tet active). */
+/* Device scratch for a mesh of num_tets tetrahedra (worst case: every tet active; about 160 bytes per tet). */
 int p3d_mt_workspace_bytes(int64_t num_vertices, int64_t num_tets, size_t* bytes);
 
 /* Phase 1: orientation fix (tets is IN/OUT), classification of every tet against sdf > 0, the sorted unique edges
@@ -43,7 +44,8 @@ int p3d_mt_prepare(const float* vertices, int64_t num_vertices, int64_t* tets, i
 
 /* Phase 2 (after p3d_mt_prepare on the same ws): write the interpolated vertices [V,3] f32, the endpoint pair of every
  * vertex [V,2] i64 (nullable; the Python wrapper uses it to rebuild the vertices with autograd when gradients are
- * needed), the faces [F,3] i64 and the tet index of every face [F] i64 (nullable). */
+ * needed), the faces [F,3] i64 and the tet index of every face [F] i64 (nullable).  `tets` is the array p3d_mt_prepare
+ * corrected. */
 int p3d_mt_emit(const float* vertices, const int64_t* tets, const float* sdf, void* ws, float* out_vertices,
                 int64_t* out_edge_pairs, int64_t* out_faces, int64_t* out_tet_idx, void* stream);
 

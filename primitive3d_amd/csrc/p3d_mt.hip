@@ -8,16 +8,17 @@
 //   k_mt_classify   per tet: orientation fix in place (:147-148), occupancy case (:151-154, :194-196); the wave's ballot
 //                   of active tets and its popcount are all that is kept about activity
 //   (scan)          over the wave counts (nt / 64 words): slot of a wave's first active tet
-//   k_mt_edges      per active tet: six sorted edge keys  lo << hb | hi  (:157-159, hb = bits of a point index) + where
-//                   they came from
-//   (radix sort)    keys ascending = torch.unique's lexicographic row order (:160); 2 hb bits, onesweep above 64 Ki keys
-//   k_mt_flags      first key of every run whose endpoints differ in occupancy = one output vertex (:163-168)
-//   (scan)          vertex id = rank of that run
-//   k_mt_map        vertex id (or -1) of every (tet, edge) slot (:169)
-//   k_mt_vertices   interpolation with the reference's float32 operation order (:178-190)
-//   k_mt_faces      triangles by the 16-case table, one-triangle tets first (:205-224), tet index per face (:226-234)
+//   k_mt_edges      per active tet: its CROSSING edges (endpoints differ in occupancy: the only ones that become
+//                   vertices, :163-168) as keys  lo << hb | hi  (:157-159, hb = bits of a point index) into a hash set
+//   (select)        the distinct keys out of the hash table
+//   (radix sort)    of the distinct keys only (V of them, not 6 per active tet): ascending = their order among
+//                   torch.unique's lexicographically sorted rows (:160), so the rank of a key IS its vertex id (:165-170)
+//   k_mt_vertices   interpolation with the reference's float32 operation order (:178-190), one thread per sorted key
+//   k_mt_ranks      every sorted key leaves its rank (= vertex id) at its slot of the hash table
+//   k_mt_faces      triangles by the 16-case table, one-triangle tets first (:205-224), tet index per face (:226-234);
+//                   8 lanes per tet: six look up the ids of its edges (one probe each), the corners pick by shuffle
 //
-// HBM-bound integer work; no MFMA.  Scans and the sort are rocPRIM device primitives.
+// HBM-bound integer work; no MFMA.  Scans, the selection and the sort are rocPRIM device primitives.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -50,31 +51,42 @@ __device__ const unsigned char k_edge_a[6] = {0, 0, 0, 1, 1, 2};
 __device__ const unsigned char k_edge_b[6] = {1, 2, 3, 2, 3, 3};
 
 struct MtWs {  // byte offsets into the workspace
-    size_t hdr, occ, cas, wmask, wcnt, wbase, vlist, keys_a, keys_b, vals_a, vals_b, cs, map, tcount, tscan, temp, temp_bytes,
-        total;
+    size_t hdr, occ, cas, wmask, wcnt, wbase, vlist, tcount, tscan, table, rank, uniq, sorted, temp, temp_bytes, total;
 };
 enum { M_NVALID = 0, M_V = 1, M_N1 = 2, M_N2 = 3 };
+constexpr u64 kEmpty = ~0ull;   // (no key: lo < hi < 2^32 and hb <= 32)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// merge sort only for small inputs: the 2 hb <= 64 key bits are 6-8 onesweep passes, cheaper than ~10 merge passes
-// from 64 Ki keys on (measured: tools/bench_next.py)
-constexpr size_t kMergeSortLimit = 65536;
+// hash set of the crossing edges: a power of two >= 6 slots per active tet (a tet has at most 4 crossing edges, and an
+// edge is shared by several tets: the load stays well below 2/3)
+inline size_t table_slots(int64_t nvalid) {
+    size_t s = 1024;
+    while (s < (size_t)nvalid * 6) s <<= 1;
+    return s;
+}
+
+struct NotEmpty {
+    __device__ bool operator()(const u64& k) const { return k != kEmpty; }
+};
+
+// merge sort only for small inputs (rocPRIM's default limit is 1 Mi keys)
+constexpr size_t kMergeSortLimit = 262144;
 using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config,
                                               kMergeSortLimit>;
 
 size_t temp_bytes_for(int64_t nt) {
     // the largest temporary any of the primitives asks for at the worst-case sizes
     size_t a = 0, a2 = 0, b = 0, c = 0, d = 0;
-    const size_t n6 = (size_t)nt * 6;
-    (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, a, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr, n6,
-                                                0u, 64u, (hipStream_t)0);
-    (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, a2, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr,
-                                                std::min(n6, kMergeSortLimit), 0u, 64u, (hipStream_t)0);
+    const size_t n4 = (size_t)nt * 4;
+    (void)rocprim::radix_sort_keys<SortConfig>(nullptr, a, (u64*)nullptr, (u64*)nullptr, n4, 0u, 64u, (hipStream_t)0);
+    (void)rocprim::radix_sort_keys<SortConfig>(nullptr, a2, (u64*)nullptr, (u64*)nullptr, std::min(n4, kMergeSortLimit), 0u,
+                                               64u, (hipStream_t)0);
     a = std::max(a, a2);
-    (void)rocprim::exclusive_scan(nullptr, b, (u32*)nullptr, (u32*)nullptr, 0u, (size_t)(nt + 63) / 64, rocprim::plus<u32>(),
+    (void)rocprim::inclusive_scan(nullptr, b, (u32*)nullptr, (u32*)nullptr, (size_t)(nt + 63) / 64, rocprim::plus<u32>(),
                                   (hipStream_t)0);
-    (void)rocprim::inclusive_scan(nullptr, c, (u32*)nullptr, (u32*)nullptr, n6, rocprim::plus<u32>(), (hipStream_t)0);
+    (void)rocprim::select(nullptr, c, (u64*)nullptr, (u64*)nullptr, (u64*)nullptr, table_slots(nt), NotEmpty(),
+                          (hipStream_t)0);
     (void)rocprim::exclusive_scan(nullptr, d, (u64*)nullptr, (u64*)nullptr, 0ull, (size_t)nt, rocprim::plus<u64>(),
                                   (hipStream_t)0);
     return std::max(std::max(a, b), std::max(c, d));
@@ -82,7 +94,7 @@ size_t temp_bytes_for(int64_t nt) {
 
 MtWs make_ws(int64_t nv, int64_t nt) {
     MtWs w;
-    const size_t n = (size_t)std::max<int64_t>(nt, 1), n6 = n * 6, nw = (n + 63) / 64;
+    const size_t n = (size_t)std::max<int64_t>(nt, 1), nw = (n + 63) / 64;
     const size_t occ_words = ((size_t)std::max<int64_t>(nv, 1) + kBlock - 1) / kBlock * (kBlock / 64);
     size_t o = 0;
     auto take = [&](size_t bytes) {
@@ -97,14 +109,12 @@ MtWs make_ws(int64_t nv, int64_t nt) {
     w.wcnt = take(nw * 4);
     w.wbase = take(nw * 4);
     w.vlist = take(n * 4);
-    w.keys_a = take(n6 * 8);
-    w.keys_b = take(n6 * 8);
-    w.vals_a = take(n6 * 4);
-    w.vals_b = take(n6 * 4);
-    w.cs = take(n6 * 4);
-    w.map = take(n6 * 4);
     w.tcount = take(n * 8);
     w.tscan = take(n * 8);
+    w.table = take(table_slots((int64_t)n) * 8);
+    w.rank = take(table_slots((int64_t)n) * 4);
+    w.uniq = take(n * 4 * 8);
+    w.sorted = take(n * 4 * 8);
     w.temp_bytes = temp_bytes_for((int64_t)n);
     w.temp = take(w.temp_bytes);
     w.total = o;
@@ -171,52 +181,45 @@ __global__ void __launch_bounds__(kBlock) k_mt_classify(const float* __restrict_
     }
 }
 
-__global__ void k_mt_nvalid(const u32* __restrict__ wcnt, const u32* __restrict__ wbase, int64_t nw, u64* __restrict__ hdr) {
-    hdr[M_NVALID] = nw > 0 ? (u64)wbase[nw - 1] + wcnt[nw - 1] : 0ull;
+__device__ inline u64 mix64(u64 k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    return k;
+}
+
+__device__ inline u64 edge_key(int64_t a, int64_t b, unsigned hb) {   // sorted pair (:67-83)
+    return a < b ? ((u64)a << hb | (u64)b) : ((u64)b << hb | (u64)a);
 }
 
 __global__ void __launch_bounds__(kBlock) k_mt_edges(const int64_t* __restrict__ tets, int64_t nt,
                                                      const unsigned char* __restrict__ cas, const u64* __restrict__ wmask,
                                                      const u32* __restrict__ wbase, u32* __restrict__ vlist,
-                                                     u64* __restrict__ keys, u32* __restrict__ vals, u64* __restrict__ tcount,
+                                                     u64* __restrict__ table, u64 table_mask, u64* __restrict__ tcount,
                                                      unsigned hb) {
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= nt) return;
     const u64 m = wmask[t >> 6];
     const u32 lane = (u32)(t & 63);
     if (!((m >> lane) & 1ull)) return;
-    const u32 s = wbase[t >> 6] + (u32)__popcll(m & ((1ull << lane) - 1ull));   // rank among the active tets (tet order)
+    // rank among the active tets, in tet order (wbase = inclusive scan of the wave counts)
+    const u32 s = wbase[t >> 6] - (u32)__popcll(m) + (u32)__popcll(m & ((1ull << lane) - 1ull));
     vlist[s] = (u32)t;
     const int64_t idx[4] = {tets[4 * t], tets[4 * t + 1], tets[4 * t + 2], tets[4 * t + 3]};
+    const u32 c = cas[t];
 #pragma unroll
     for (int e = 0; e < 6; ++e) {
-        const u64 a = (u64)idx[k_edge_a[e]], b = (u64)idx[k_edge_b[e]];
-        keys[(size_t)s * 6 + e] = a < b ? (a << hb | b) : (b << hb | a);   // sorted pair (:67-83)
-        vals[(size_t)s * 6 + e] = s * 6u + (u32)e;
+        if (((c >> k_edge_a[e]) ^ (c >> k_edge_b[e])) & 1u) {   // endpoints differ in occupancy (:163)
+            const u64 key = edge_key(idx[k_edge_a[e]], idx[k_edge_b[e]], hb);
+            u64 h = mix64(key) & table_mask;
+            for (;;) {
+                const u64 prev = atomicCAS((unsigned long long*)&table[h], (unsigned long long)kEmpty, (unsigned long long)key);
+                if (prev == kEmpty || prev == key) break;
+                h = (h + 1) & table_mask;
+            }
+        }
     }
-    tcount[s] = k_num_tri[cas[t]] == 1 ? 1ull : (1ull << 32);   // low word: one-triangle tets, high word: two-triangle tets
-}
-
-__device__ inline bool key_crosses(const u32* __restrict__ occ, u64 k, unsigned hb) {
-    return occ_bit(occ, k >> hb) != occ_bit(occ, k & ((1ull << hb) - 1ull));   // :163
-}
-
-__global__ void __launch_bounds__(kBlock) k_mt_flags(const u64* __restrict__ keys, int64_t n6, const u32* __restrict__ occ,
-                                                     unsigned hb, u32* __restrict__ flag) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n6) return;
-    const u64 k = keys[i];
-    const bool head = i == 0 || keys[i - 1] != k;
-    flag[i] = (head && key_crosses(occ, k, hb)) ? 1u : 0u;
-}
-
-__global__ void __launch_bounds__(kBlock) k_mt_map(const u64* __restrict__ keys, const u32* __restrict__ vals, int64_t n6,
-                                                   const u32* __restrict__ occ, const u32* __restrict__ cs, unsigned hb,
-                                                   int32_t* __restrict__ map) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n6) return;
-    // every element of a run sees the run's own count (only its first element was flagged): :164-169
-    map[vals[i]] = key_crosses(occ, keys[i], hb) ? (int32_t)(cs[i] - 1u) : -1;
+    tcount[s] = k_num_tri[c] == 1 ? 1ull : (1ull << 32);   // low word: one-triangle tets, high word: two-triangle tets
 }
 
 struct Sizes {   // what phase 1 found; kept in the last 64 bytes of the workspace's 256-byte header for phase 2
@@ -224,9 +227,9 @@ struct Sizes {   // what phase 1 found; kept in the last 64 bytes of the workspa
 };
 constexpr size_t kSizesOffset = 192;
 
-__global__ void k_mt_totals(const u32* __restrict__ cs, int64_t n6, const u64* __restrict__ tcount,
-                            const u64* __restrict__ tscan, int64_t nv, int64_t nt, int64_t nvalid, u64* __restrict__ hdr) {
-    const u64 v = n6 > 0 ? (u64)cs[n6 - 1] : 0ull;
+__global__ void k_mt_totals(const u64* __restrict__ nuniq, const u64* __restrict__ tcount, const u64* __restrict__ tscan,
+                            int64_t nv, int64_t nt, int64_t nvalid, u64* __restrict__ hdr) {
+    const u64 v = nvalid > 0 ? *nuniq : 0ull;
     const u64 both = nvalid > 0 ? tscan[nvalid - 1] + tcount[nvalid - 1] : 0ull;
     hdr[M_V] = v;
     hdr[M_N1] = both & 0xffffffffull;
@@ -235,15 +238,13 @@ __global__ void k_mt_totals(const u32* __restrict__ cs, int64_t n6, const u64* _
     *sz = Sizes{nv, nt, nvalid, (int64_t)v, (int64_t)(both & 0xffffffffull), (int64_t)(both >> 32)};
 }
 
-__global__ void __launch_bounds__(kBlock) k_mt_vertices(const u64* __restrict__ keys, const u32* __restrict__ flag,
-                                                        const u32* __restrict__ cs, int64_t n6, unsigned hb,
+__global__ void __launch_bounds__(kBlock) k_mt_vertices(const u64* __restrict__ sorted, int64_t nkeys, unsigned hb,
                                                         const float* __restrict__ vertices, const float* __restrict__ sdf,
                                                         float* __restrict__ out, int64_t* __restrict__ pairs) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n6 || !flag[i]) return;
-    const u64 k = keys[i];
+    const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (v >= nkeys) return;
+    const u64 k = sorted[v];
     const int64_t a = (int64_t)(k >> hb), b = (int64_t)(k & ((1ull << hb) - 1ull));
-    const size_t v = (size_t)cs[i] - 1;
     // :178-190, operation for operation in float32: [s_a, -s_b], their sum, the flipped pair divided by it, then
     // p_a * w0 + p_b * w1 (build flag -ffp-contract=off keeps the products and the sum separately rounded)
     const float sa = sdf[a], nsb = sdf[b] * -1.0f;
@@ -258,22 +259,51 @@ __global__ void __launch_bounds__(kBlock) k_mt_vertices(const u64* __restrict__ 
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_mt_faces(const u32* __restrict__ vlist, const unsigned char* __restrict__ cas,
-                                                     const u64* __restrict__ tscan, const int32_t* __restrict__ map,
-                                                     int64_t nvalid, const u64* __restrict__ hdr,
-                                                     int64_t* __restrict__ faces, int64_t* __restrict__ tet_idx) {
-    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (s >= nvalid) return;
-    const u32 t = vlist[s];
-    const int c = cas[t];
-    const int n = k_num_tri[c];
-    const u64 sc = tscan[s];
-    // one-triangle tets first, in tet order, then the two-triangle tets (:205-224)
-    const int64_t f0 = n == 1 ? (int64_t)(sc & 0xffffffffull) : (int64_t)hdr[M_N1] + 2 * (int64_t)(sc >> 32);
-    for (int k = 0; k < n; ++k) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) faces[(f0 + k) * 3 + j] = (int64_t)map[(size_t)s * 6 + k_tri_table[c][3 * k + j]];
-        if (tet_idx) tet_idx[f0 + k] = (int64_t)t;
+// slot of a key that IS in the hash set
+__device__ inline u64 find_slot(const u64* __restrict__ table, u64 table_mask, u64 key) {
+    u64 h = mix64(key) & table_mask;
+    while (table[h] != key) h = (h + 1) & table_mask;
+    return h;
+}
+
+// vertex id of every distinct crossing edge = its rank among the sorted keys (:165-171), left where the faces find it
+__global__ void __launch_bounds__(kBlock) k_mt_ranks(const u64* __restrict__ sorted, int64_t nkeys,
+                                                     const u64* __restrict__ table, u64 table_mask, u32* __restrict__ rank) {
+    const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (v >= nkeys) return;
+    rank[find_slot(table, table_mask, sorted[v])] = (u32)v;
+}
+
+// 8 lanes per active tet: lane e < 6 looks up edge e's vertex id, lane k < 3n writes corner k of the tet's triangles
+__global__ void __launch_bounds__(kBlock) k_mt_faces(const int64_t* __restrict__ tets, const u32* __restrict__ vlist,
+                                                     const unsigned char* __restrict__ cas, const u64* __restrict__ tscan,
+                                                     const u64* __restrict__ table, u64 table_mask,
+                                                     const u32* __restrict__ rank, unsigned hb, int64_t nvalid,
+                                                     const u64* __restrict__ hdr, int64_t* __restrict__ faces,
+                                                     int64_t* __restrict__ tet_idx) {
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t s = g >> 3;
+    const int e = (int)(g & 7);
+    const bool live = s < nvalid;
+    u32 t = 0, c = 0;
+    u32 id = 0;
+    if (live) {
+        t = vlist[s];
+        c = cas[t];
+        if (e < 6 && (((c >> k_edge_a[e]) ^ (c >> k_edge_b[e])) & 1u)) {
+            const u64 key = edge_key(tets[4 * (int64_t)t + k_edge_a[e]], tets[4 * (int64_t)t + k_edge_b[e]], hb);
+            id = rank[find_slot(table, table_mask, key)];
+        }
+    }
+    const int n = live ? k_num_tri[c] : 0;
+    const int src = (e < 3 * n) ? k_tri_table[c][e] : 0;
+    const u32 corner = (u32)__shfl((int)id, ((int)threadIdx.x & 56) + src, 64);   // (all lanes take part)
+    if (e < 3 * n) {
+        const u64 sc = tscan[s];
+        // one-triangle tets first, in tet order, then the two-triangle tets (:205-224)
+        const int64_t f0 = n == 1 ? (int64_t)(sc & 0xffffffffull) : (int64_t)hdr[M_N1] + 2 * (int64_t)(sc >> 32);
+        faces[f0 * 3 + e] = (int64_t)corner;
+        if (tet_idx && e < n) tet_idx[f0 + e] = (int64_t)t;
     }
 }
 
@@ -352,10 +382,8 @@ int p3d_mt_prepare(const float* vertices, int64_t num_vertices, int64_t* tets, i
     unsigned char* cas = (unsigned char*)(ws + w.cas);
     u64* wmask = (u64*)(ws + w.wmask);
     u32 *wcnt = (u32*)(ws + w.wcnt), *wbase = (u32*)(ws + w.wbase), *vlist = (u32*)(ws + w.vlist);
-    u64 *keys_a = (u64*)(ws + w.keys_a), *keys_b = (u64*)(ws + w.keys_b);
-    u32 *vals_a = (u32*)(ws + w.vals_a), *vals_b = (u32*)(ws + w.vals_b), *cs = (u32*)(ws + w.cs);
-    int32_t* map = (int32_t*)(ws + w.map);
     u64 *tcount = (u64*)(ws + w.tcount), *tscan = (u64*)(ws + w.tscan);
+    u64 *table = (u64*)(ws + w.table), *uniq = (u64*)(ws + w.uniq);
     void* temp = ws + w.temp;
     size_t tb = w.temp_bytes;
     const unsigned hb = index_bits(num_vertices);
@@ -370,29 +398,25 @@ int p3d_mt_prepare(const float* vertices, int64_t num_vertices, int64_t* tets, i
         else
             hipLaunchKernelGGL((k_mt_classify<false>), dim3(blocks_for(num_tets)), dim3(kBlock), 0, st, vertices, tets,
                                num_tets, (const u32*)occ, cas, wmask, wcnt);
-        HIP_TRY(rocprim::exclusive_scan(temp, tb, wcnt, wbase, 0u, (size_t)nw, rocprim::plus<u32>(), st));
-        hipLaunchKernelGGL(k_mt_nvalid, dim3(1), dim3(1), 0, st, wcnt, wbase, nw, hdr);
-        u64 nvalid = 0;
-        HIP_TRY(hipMemcpyAsync(&nvalid, hdr + M_NVALID, sizeof(u64), hipMemcpyDeviceToHost, st));
+        // inclusive: its last element is the number of active tets (a wave's first slot = its element - its count)
+        HIP_TRY(rocprim::inclusive_scan(temp, tb, wcnt, wbase, (size_t)nw, rocprim::plus<u32>(), st));
+        u32 nvalid = 0;
+        HIP_TRY(hipMemcpyAsync(&nvalid, wbase + (nw - 1), sizeof(u32), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));   // (the reference synchronises here too: tets[valid_tets], :157)
         sz.nvalid = (int64_t)nvalid;
     }
-    const int64_t n6 = sz.nvalid * 6;
     if (sz.nvalid > 0) {
+        const size_t slots = table_slots(sz.nvalid);
+        HIP_TRY(hipMemsetAsync(table, 0xff, slots * sizeof(u64), st));
         hipLaunchKernelGGL(k_mt_edges, dim3(blocks_for(num_tets)), dim3(kBlock), 0, st, tets, num_tets, cas, wmask, wbase,
-                           vlist, keys_a, vals_a, tcount, hb);
+                           vlist, table, (u64)(slots - 1), tcount, hb);
         tb = w.temp_bytes;
-        HIP_TRY(rocprim::radix_sort_pairs<SortConfig>(temp, tb, keys_a, keys_b, vals_a, vals_b, (size_t)n6, 0u, 2u * hb, st));
-        hipLaunchKernelGGL(k_mt_flags, dim3(blocks_for(n6)), dim3(kBlock), 0, st, keys_b, n6, (const u32*)occ, hb, vals_a);
-        tb = w.temp_bytes;
-        HIP_TRY(rocprim::inclusive_scan(temp, tb, vals_a, cs, (size_t)n6, rocprim::plus<u32>(), st));
-        hipLaunchKernelGGL(k_mt_map, dim3(blocks_for(n6)), dim3(kBlock), 0, st, keys_b, vals_b, n6, (const u32*)occ, cs, hb,
-                           map);
+        HIP_TRY(rocprim::select(temp, tb, table, uniq, hdr + M_V, slots, NotEmpty(), st));
         tb = w.temp_bytes;
         HIP_TRY(rocprim::exclusive_scan(temp, tb, tcount, tscan, 0ull, (size_t)sz.nvalid, rocprim::plus<u64>(), st));
     }
     // totals, and the sizes for p3d_mt_emit in the workspace header (written by the device: no upload, no wait)
-    hipLaunchKernelGGL(k_mt_totals, dim3(1), dim3(1), 0, st, cs, n6, tcount, tscan, num_vertices, num_tets, sz.nvalid, hdr);
+    hipLaunchKernelGGL(k_mt_totals, dim3(1), dim3(1), 0, st, hdr + M_V, tcount, tscan, num_vertices, num_tets, sz.nvalid, hdr);
     if (sz.nvalid > 0) {
         u64 h[4] = {0, 0, 0, 0};
         HIP_TRY(hipMemcpyAsync(h, hdr, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -410,7 +434,6 @@ int p3d_mt_prepare(const float* vertices, int64_t num_vertices, int64_t* tets, i
 
 int p3d_mt_emit(const float* vertices, const int64_t* tets, const float* sdf, void* ws_, float* out_vertices,
                 int64_t* out_edge_pairs, int64_t* out_faces, int64_t* out_tet_idx, void* stream) {
-    (void)tets;
     if (!ws_) return fail(P3D_MT_EINVAL, "null pointer%s");
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)ws_;
@@ -421,18 +444,25 @@ int p3d_mt_emit(const float* vertices, const int64_t* tets, const float* sdf, vo
     }
     const MtWs w = make_ws(sz.nv, sz.nt);
     if (sz.nvalid <= 0) return P3D_MT_OK;
-    if ((sz.nv_out > 0 && (!out_vertices || !vertices || !sdf)) || (sz.n1 + sz.n2 > 0 && !out_faces))
+    if ((sz.nv_out > 0 && (!out_vertices || !vertices || !sdf)) || (sz.n1 + sz.n2 > 0 && (!out_faces || !tets)))
         return fail(P3D_MT_EINVAL, "null output%s");
-    const int64_t n6 = sz.nvalid * 6;
     const unsigned hb = index_bits(sz.nv);
-    if (sz.nv_out > 0)
-        hipLaunchKernelGGL(k_mt_vertices, dim3(blocks_for(n6)), dim3(kBlock), 0, st, (const u64*)(ws + w.keys_b),
-                           (const u32*)(ws + w.vals_a), (const u32*)(ws + w.cs), n6, hb, vertices, sdf, out_vertices,
-                           out_edge_pairs);
+    u64 *uniq = (u64*)(ws + w.uniq), *sorted = (u64*)(ws + w.sorted);
+    const u64* table = (const u64*)(ws + w.table);
+    u32* rank = (u32*)(ws + w.rank);
+    const u64 table_mask = (u64)(table_slots(sz.nvalid) - 1);
+    if (sz.nv_out > 0) {
+        size_t tb = w.temp_bytes;
+        HIP_TRY(rocprim::radix_sort_keys<SortConfig>(ws + w.temp, tb, uniq, sorted, (size_t)sz.nv_out, 0u, 2u * hb, st));
+        hipLaunchKernelGGL(k_mt_vertices, dim3(blocks_for(sz.nv_out)), dim3(kBlock), 0, st, (const u64*)sorted, sz.nv_out, hb,
+                           vertices, sdf, out_vertices, out_edge_pairs);
+        hipLaunchKernelGGL(k_mt_ranks, dim3(blocks_for(sz.nv_out)), dim3(kBlock), 0, st, (const u64*)sorted, sz.nv_out, table,
+                           table_mask, rank);
+    }
     if (sz.n1 + sz.n2 > 0)
-        hipLaunchKernelGGL(k_mt_faces, dim3(blocks_for(sz.nvalid)), dim3(kBlock), 0, st, (const u32*)(ws + w.vlist),
-                           (const unsigned char*)(ws + w.cas), (const u64*)(ws + w.tscan), (const int32_t*)(ws + w.map),
-                           sz.nvalid, (const u64*)(ws + w.hdr), out_faces, out_tet_idx);
+        hipLaunchKernelGGL(k_mt_faces, dim3(blocks_for(sz.nvalid * 8)), dim3(kBlock), 0, st, tets, (const u32*)(ws + w.vlist),
+                           (const unsigned char*)(ws + w.cas), (const u64*)(ws + w.tscan), table, table_mask,
+                           (const u32*)rank, hb, sz.nvalid, (const u64*)(ws + w.hdr), out_faces, out_tet_idx);
     HIP_TRY(hipGetLastError());
     return P3D_MT_OK;
 }
