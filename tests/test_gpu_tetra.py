@@ -108,3 +108,51 @@ def test_example_scripts_run(gpu, script, args):
     out = subprocess.run([sys.executable, str(root / "examples" / script), *args], capture_output=True, text=True,
                          timeout=600, cwd=str(root))
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+
+
+def test_unaligned_tets_and_repeated_emit(gpu, built):
+    """A tet array that starts 8 bytes off a 16-byte boundary takes the scalar-load classify kernel; p3d_mt_emit called a
+    second time (without the host-side copy of the sizes, which the first call consumed) reads them from the workspace."""
+    import ctypes
+    from primitive3d_amd import tetrahedra as T
+    P, tets_np, sdf = _grid_tets(10, 3)
+    flat = torch.zeros(tets_np.size + 1, dtype=torch.int64, device=gpu)
+    tets = flat[1:].view(-1, 4)
+    tets.copy_(torch.from_numpy(tets_np))
+    assert tets.data_ptr() % 16 == 8
+    pts, s = torch.from_numpy(P).to(gpu), torch.from_numpy(sdf).to(gpu)
+    v, f, ti = built.marching_tetrahedras(pts, tets, s, True)
+    rv, rf, rti, rta = mt_oracle(P, tets_np, sdf)
+    _same(v.cpu().numpy(), f.cpu().numpy(), ti.cpu().numpy(), tets.cpu().numpy(), rv, rf, rti, rta)
+    # the C ABI directly: prepare once, emit twice
+    L = T.lib()
+    nb = ctypes.c_size_t(0)
+    assert L.p3d_mt_workspace_bytes(pts.shape[0], tets.shape[0], ctypes.byref(nb)) == 0
+    ws = torch.empty(nb.value, dtype=torch.uint8, device=gpu)
+    nv, nf = ctypes.c_int64(0), ctypes.c_int64(0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert L.p3d_mt_prepare(p(pts), pts.shape[0], p(tets), tets.shape[0], p(s), p(ws), ctypes.byref(nv), ctypes.byref(nf), st) == 0
+    assert (nv.value, nf.value) == (rv.shape[0], rf.shape[0])
+    for _ in range(2):
+        ov = torch.empty((nv.value, 3), device=gpu)
+        of = torch.empty((nf.value, 3), dtype=torch.int64, device=gpu)
+        assert L.p3d_mt_emit(p(pts), p(tets), p(s), p(ws), p(ov), None, p(of), None, st) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(ov.cpu().numpy(), rv) and np.array_equal(of.cpu().numpy(), rf)
+
+
+def test_many_tets_around_one_edge(gpu, built):
+    """A fan of K tetrahedra around one crossing edge (every tet inserts the same key into the hash set) plus a ring of
+    crossing edges each shared by two tets."""
+    K = 300
+    ang = np.linspace(0, 2 * np.pi, K, endpoint=False)
+    ring = np.stack([np.cos(ang), np.sin(ang), np.zeros(K)], 1)
+    P = np.concatenate([[[0, 0, -1.0], [0, 0, 1.0]], ring]).astype(np.float32)
+    T = np.stack([np.zeros(K), np.ones(K), 2 + np.arange(K), 2 + (np.arange(K) + 1) % K], 1).astype(np.int64)
+    sdf = np.concatenate([[-1.0, 0.7], 0.3 + 0.2 * np.cos(3 * ang)]).astype(np.float32)
+    tets = torch.from_numpy(T.copy()).to(gpu)
+    v, f, ti = built.marching_tetrahedras(torch.from_numpy(P).to(gpu), tets, torch.from_numpy(sdf).to(gpu), True)
+    rv, rf, rti, rta = mt_oracle(P, T, sdf)
+    assert rv.shape[0] == K + 1
+    _same(v.cpu().numpy(), f.cpu().numpy(), ti.cpu().numpy(), tets.cpu().numpy(), rv, rf, rti, rta)
