@@ -180,7 +180,9 @@ int p3d_mc_export_plane_records(const void* ws, int64_t rx, int64_t ry, int64_t 
  * only, 2 = around every stage.  Events are recorded on the stream passed to count/emit.
  * p3d_mc_profile_read synchronises those events and returns the per-stage durations (ms, -1 = not
  * recorded) of the most recent call; it returns the number of stages (11; pass n >= 11).  The dominant
- * kernel's events ride on its own dispatch packet (hipExtLaunchKernel), so timing it does not perturb the stream. */
+ * kernel's events ride on its own dispatch packet (hipExtLaunchKernel), so timing it does not perturb the stream.
+ * The profiling state is one per process and NOT synchronised: enable it only while a single thread on a single
+ * stream calls the library (bench.py, tools/); the extraction calls themselves are re-entrant with it off. */
 int p3d_mc_profile_enable(int mode);
 int p3d_mc_profile_read(float* stage_ms, int n);
 const char* p3d_mc_profile_stage_name(int stage);

@@ -15,7 +15,12 @@ def pytest_configure(config):
     # test modules import the package at collection time and the package refuses to import without its native
     # artefacts: (re)build them first -- a no-op when they are up to date (they travel with the repo snapshot)
     import __graft_entry__
-    __graft_entry__.load_build_module().build_all()
+    try:
+        __graft_entry__.load_build_module().build_all()
+    except FileNotFoundError as e:
+        # no hipcc on this machine: the oracle / gloo tests still run; everything that needs the libraries fails at
+        # import or in the `built` fixture (there is no fallback to hide behind)
+        print(f"conftest: native build skipped ({e})", file=sys.stderr)
 
 
 @pytest.fixture(scope="session")

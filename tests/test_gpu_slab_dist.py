@@ -20,15 +20,19 @@ from oracle import canonical_mesh, oracle_extract  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out_dir, shape, thresh, lower, upper):
+def _worker(rank, world, port, out_dir, shape, thresh, lower, upper, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    index = rank if backend == "nccl" else 0   # RCCL: one GPU per rank; gloo: all ranks share the one GPU
+    torch.cuda.set_device(index)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", index))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from primitive3d_amd import capi
     from primitive3d_amd.fields import perlin_grid
     from primitive3d_amd.slab import SlabExtractor
     from tests.ws_keys import vertex_keys_from_workspace
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", index)
     ex = SlabExtractor(shape, rank, world, dev)
     # (generated on the CPU like the oracle's input: the device generator may differ in the last bit)
     ex.fill_local(lambda x0, x1: perlin_grid(shape, period=12, seed=5, x0=x0, x1=x1).to(dev))
@@ -53,10 +57,22 @@ def _worker(rank, world, port, out_dir, shape, thresh, lower, upper):
 @pytest.mark.parametrize("world,shape", [(2, (61, 21, 150)), (3, (61, 21, 150)), (8, (61, 21, 150)),
                                          (8, (208, 21, 150))])   # 8 ranks: thin slabs, and slabs streamed in two parts
 def test_distributed_extract_on_one_gpu(tmp_path, gpu, world, shape):
+    _run_and_compare(tmp_path, world, shape, "gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (this box has one)")
+@pytest.mark.parametrize("shape", [(61, 21, 150), (208, 21, 150)])
+def test_distributed_extract_over_rccl(tmp_path, gpu, shape):
+    """The same check with the real transport: backend "nccl" (= RCCL), one GPU per rank, as many ranks as the node has
+    GPUs (up to 8).  Skipped on the single-GPU test box; runs wherever a multi-GPU node executes `pytest -m gpu`."""
+    _run_and_compare(tmp_path, min(8, torch.cuda.device_count()), shape, "nccl")
+
+
+def _run_and_compare(tmp_path, world, shape, backend):
     from primitive3d_amd.fields import perlin_grid
     thresh, lower, upper = 0.02, [0.5, -1.0, 2.0], [3.0, 4.0, 9.0]
     port = 29600 + (os.getpid() % 2000) + world
-    mp.spawn(_worker, args=(world, port, str(tmp_path), shape, thresh, lower, upper), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), shape, thresh, lower, upper, backend), nprocs=world, join=True)
     parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
     assert [int(p["base"]) for p in parts] == list(np.cumsum([0] + [len(p["v"]) for p in parts[:-1]]))
     hip = (np.concatenate([p["v"] for p in parts]), np.concatenate([p["f"] for p in parts]),
