@@ -12,7 +12,8 @@ device-resident fp32 grid.  Workload per rank is fixed at 2^27 voxels (weak scal
   N=8  1024^3          (BASELINE.json configs[3])
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant
 kernel (hipEvent-timed inside the library, on the launch stream) and `cpu_baseline` (the CPU oracle
-restatement of the reference kernels, 1 core, timed on the same grid; N=1 only).
+restatement of the reference kernels on all host cores and on one thread, an `import mcubes` attempt, and the
+whole-mesh comparison with the GPU's result; N=1 only).  `--config c2|c4|c5` selects the other single-GPU workloads.
 """
 import argparse
 import json
