@@ -1524,8 +1524,9 @@ void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const 
                     uint2* rec, u64* cursors, u64* zero_next, float* scratch, u32 region_rows, u32 store_rows, int x_lo,
                   int x_hi,
                     hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
-    // three tile geometries (all hold 32 unit words per wave-plane): long rows (8 chunks x 3 rows per wave), rows of
-    // 3-4 chunks (rz <= 256: 4 chunks x 7 rows -- the 8-chunk tile would be half empty), short rows (2 chunks x 15 rows)
+    // tile geometries (32 unit words per wave-plane unless noted): long rows (8 chunks x 3 rows per wave), rows of 3-4
+    // chunks (rz <= 256: 4 chunks x 7 rows -- the 8-chunk tile would be half empty -- or, for a single small grid,
+    // 16-unit tiles of 4 chunks x 3 rows), short rows (2 chunks x 15 rows)
     if (d.ncz >= 5)
         launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
                               store_rows, x_lo, x_hi, ev0, ev1, st);
@@ -1534,6 +1535,11 @@ void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const 
              //  better off with more, half-empty tiles than with 2-plane slabs)
              ((d.ry + 27) / 28) * (d.stack ? d.nitems : 1) * ((x_hi - x_lo + 7) / 8) >= 1024)
         launch_fused<T, 4, 7>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                              store_rows, x_lo, x_hi, ev0, ev1, st);
+    else if (d.ncz >= 3 && env_int("P3D_FUSED_SMALL16", 1))
+        // a single small grid: 16-unit tiles (4 chunks x 3 rows + halo row) -- twice the waves of the 8-chunk tile, none
+        // of them half empty
+        launch_fused<T, 4, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
                               store_rows, x_lo, x_hi, ev0, ev1, st);
     else if (d.ncz >= 3)
         launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,

@@ -9,7 +9,11 @@ gpu = torch.device("cuda", 0)
 n_ok = 0
 for it in range(int(os.environ.get("N", "60"))):
     rx, ry = int(rng.integers(2, 40)), int(rng.integers(2, 40))
-    rz = int(rng.choice([rng.integers(2, 70), rng.integers(60, 140), rng.integers(250, 700), rng.integers(2040, 2200)]))
+    rz = int(rng.choice([rng.integers(2, 70), rng.integers(60, 140), rng.integers(129, 257), rng.integers(250, 700),
+                         rng.integers(2040, 2200)]))
+    if os.environ.get("RZ"):   # e.g. RZ=129,257: only rows of that length range
+        lo, hi = (int(v) for v in os.environ["RZ"].split(","))
+        rz = int(rng.integers(lo, hi))
     kind = rng.integers(0, 3)
     if kind == 0:
         g = rng.standard_normal((rx, ry, rz)).astype(np.float32)
