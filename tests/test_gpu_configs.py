@@ -238,3 +238,23 @@ def test_c4_shape_two_slabs_of_1024_squared(gpu):
     f = torch.cat([r.faces for r in res])
     mesh_properties(v, f)
     assert float(res[0].vertices[:, 0].max()) < 128.0 and float(res[1].vertices[:, 0].min()) >= 128.0
+
+
+def test_grid_above_4gib(gpu, built):
+    """1280 x 1024 x 1024 fp32 = 5 GiB: byte offsets into the grid exceed 32 bits (the streaming kernel re-bases its
+    buffer descriptor per plane) and 3 * voxels is 2 x the reference's int32 index range (marching_cubes.cu:98,161).
+    Counts against the independent torch count, mesh properties, and the last planes really contribute."""
+    from primitive3d_amd.fields import perlin_grid
+    shape = (1280, 1024, 1024)
+    g = perlin_grid(shape, period=64, seed=1, device=gpu)
+    assert g.numel() * 4 > 2 ** 32
+    v, f = built.marching_cubes(g, 0.0)
+    torch.cuda.synchronize()
+    assert (v.shape[0], f.shape[0]) == torch_counts(g, 0.0)
+    mesh_properties(v, f)
+    assert float(v[:, 0].max()) > 1270.0 and float(v[:, 0].min()) < 1.0
+    # the part beyond the 4 GiB mark alone, as its own grid: same triangles as the whole grid's there (shifted in x)
+    x0 = 1100
+    vt, ft = built.marching_cubes(g[x0:].contiguous(), 0.0)
+    sel = (v[f.long()][:, :, 0].min(dim=1).values >= x0)   # triangles of the whole mesh with all corners at x >= x0
+    assert int(sel.sum()) == ft.shape[0]
