@@ -1,18 +1,19 @@
-"""`create_raycaster` with the reference's signature (prim3d/utility/ray_cast.py:6-27): the BVH build takes host tensors
-(this build has no OptiX: `enable_optix` is False, so vertices and faces are moved to the CPU exactly as the reference's
-wrapper does, :21-25) and returns the native `RayCaster`, whose `invoke(origins, directions, depths, normals,
-primitives_ids)` fills the three caller-allocated CUDA tensors (nearest hit within 10 units; depth 10 / normal 0 /
-id -1 on a miss).  Native side: csrc/p3d_rc.hip behind include/p3d_rc.h."""
+"""`create_raycaster(vertices, faces)` as in the reference (prim3d/utility/ray_cast.py:6-27): returns the native
+`RayCaster`, whose `invoke(origins, directions, depths, normals, primitives_ids)` fills three caller-allocated CUDA
+tensors (nearest hit within 10 units; depth 10 / normal 0 / id -1 on a miss).
+
+This build has no OptiX (`libPrim3D.enable_optix` is False), so of the reference wrapper's two placements only one
+exists: the BVH is built on the host, hence a mesh living on the GPU is brought to the CPU first (:21-25).  Native side:
+csrc/p3d_rc.hip behind include/p3d_rc.h."""
 import torch
 
 from . import libPrim3D as _C
 
 
+def _on_host(t: torch.Tensor) -> torch.Tensor:
+    return t.cpu() if t.is_cuda else t
+
+
 def create_raycaster(vertices: torch.Tensor, faces: torch.Tensor) -> _C.RayCaster:
-    if _C.enable_optix:  # never true in this build; kept so that the function reads like the reference's
-        vertices = vertices.cuda() if not vertices.is_cuda else vertices
-        faces = faces.cuda() if not faces.is_cuda else faces
-    else:
-        vertices = vertices.cpu() if vertices.is_cuda else vertices
-        faces = faces.cpu() if faces.is_cuda else faces
-    return _C.create_raycaster(vertices, faces)
+    assert not _C.enable_optix, "this build has no OptiX path"
+    return _C.create_raycaster(_on_host(vertices), _on_host(faces))
