@@ -51,6 +51,17 @@ def small_cases():
     c["inf_10x9x66"] = (with_infs((10, 9, 66), 13), 0.0, None, None)
     c["all_inside_4x4x4"] = (np.ones((4, 4, 4), np.float32), 0.0, None, None)
     c["all_outside_4x4x4"] = (np.zeros((4, 4, 4), np.float32), 0.0, None, None)
+    # thresholds that no value exceeds / every value exceeds / that compare false with everything (cu:25: d > thresh)
+    c["thresh_plus_inf"] = (noise((6, 5, 70), 14), float("inf"), None, None)
+    c["thresh_minus_inf"] = (noise((6, 5, 70), 15), float("-inf"), None, None)
+    c["thresh_nan"] = (noise((6, 5, 70), 16), float("nan"), None, None)
+    # subnormal samples and a subnormal threshold: compares, differences and the IEEE divide must not flush to zero
+    c["subnormal_7x6x66"] = ((noise((7, 6, 66), 17).astype(np.float64) * 1e-41).astype(np.float32), 0.0, None, None)
+    c["subnormal_thresh_7x6x66"] = ((noise((7, 6, 66), 18).astype(np.float64) * 1e-41).astype(np.float32), 2e-42, None,
+                                    None)
+    # huge magnitudes: d1 - d0 overflows to inf on many edges (dt = finite / inf = 0)
+    c["huge_6x6x66"] = (np.clip(noise((6, 6, 66), 19).astype(np.float64) * 3e38, -3.3e38, 3.3e38).astype(np.float32), 0.0,
+                        None, None)
     c["perlin48"] = (perlin_grid(48, period=16, seed=3).numpy(), 0.0, None, None)
     c["perlin_40x24x96_thr"] = (perlin_grid((40, 24, 96), period=16, seed=4).numpy(), 0.05, [0, 0, 0], [2.0, 2.0, 2.0])
     return c
