@@ -156,3 +156,24 @@ def test_many_tets_around_one_edge(gpu, built):
     rv, rf, rti, rta = mt_oracle(P, T, sdf)
     assert rv.shape[0] == K + 1
     _same(v.cpu().numpy(), f.cpu().numpy(), ti.cpu().numpy(), tets.cpu().numpy(), rv, rf, rti, rta)
+
+
+def test_special_sdf_values(gpu, built):
+    """Exact zeros (outside: sdf > 0 is false, :151), infinities, NaNs and subnormals in the SDF: same topology as the
+    oracle, positions equal with NaN == NaN (a NaN's payload is not specified)."""
+    P, T, sdf = _grid_tets(9, 21)
+    rng = np.random.default_rng(5)
+    pick = rng.permutation(len(sdf))
+    sdf[pick[:60]] = 0.0
+    sdf[pick[60:90]] = np.inf
+    sdf[pick[90:120]] = -np.inf
+    sdf[pick[120:150]] = np.nan
+    sdf[pick[150:220]] *= np.float32(1e-42)
+    tets = torch.from_numpy(T.copy()).to(gpu)
+    v, f, ti = built.marching_tetrahedras(torch.from_numpy(P).to(gpu), tets, torch.from_numpy(sdf).to(gpu), True)
+    with np.errstate(all="ignore"):
+        rv, rf, rti, rta = mt_oracle(P, T, sdf)
+    assert np.array_equal(tets.cpu().numpy(), rta) and np.array_equal(f.cpu().numpy(), rf)
+    assert np.array_equal(ti.cpu().numpy(), rti)
+    assert np.array_equal(v.cpu().numpy(), rv, equal_nan=True)
+    assert np.isnan(rv).any() and np.isfinite(rv).any()
