@@ -265,6 +265,7 @@ int p3d_rc_create(const float* vertices, int64_t num_vertices, const int32_t* fa
             t.b[k] = vertices[(size_t)ib * 3 + k];
             t.c[k] = vertices[(size_t)ic * 3 + k];
             t.cen[k] = (t.a[k] + t.b[k] + t.c[k]) / 3.0f;   // triangle.h:40-46
+            if (!(t.cen[k] == t.cen[k])) t.cen[k] = 0.0f;   // NaN coordinates: keep the split comparator a strict weak order
         }
         t.idx = (int32_t)f;
     }

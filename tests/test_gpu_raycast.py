@@ -103,3 +103,29 @@ def test_far_hits_are_misses_and_errors(gpu, built):
     with pytest.raises(RuntimeError, match="origins must be a CUDA tensor"):
         rc.invoke(o, o.to(gpu), torch.empty(2, device=gpu), torch.empty(2, 3, device=gpu),
                   torch.empty(2, dtype=torch.int32, device=gpu))
+
+
+def test_degenerate_triangles_and_duplicate_centroids(gpu, built):
+    """Zero-area triangles (their intersector yields NaN, which `t < best` never accepts, triangle.h:16-33), many
+    triangles with one and the same centroid (the median split cannot separate them) and a few NaN vertices: the good
+    triangles are still found, exactly as brute force finds them."""
+    rng = np.random.default_rng(42)
+    ntri = 600
+    c = rng.uniform(-1, 1, (ntri, 1, 3))
+    tri = (c + rng.normal(0, 0.2, (ntri, 3, 3))).astype(np.float32)
+    tri[:40, 1] = tri[:40, 0]                      # two equal corners
+    tri[40:60] = tri[40:60, :1]                    # a point
+    tri[60:160] = tri[60]                          # 100 copies of one triangle: identical centroids
+    tri[160:165, 2, 0] = np.nan                    # NaN coordinates
+    v = tri.reshape(-1, 3)
+    f = np.arange(ntri * 3, dtype=np.int32).reshape(ntri, 3)
+    ro, rd = _rays(rng, 2000)
+    with np.errstate(all="ignore"):
+        rd_, rn, ri, second = raycast_oracle(v, f, ro, rd)
+    d, n, i = _cast(built, gpu, v, f, ro, rd)
+    assert np.array_equal(i >= 0, ri >= 0)
+    assert np.array_equal(d, rd_), "depths differ"
+    clear = (ri >= 0) & ((second - rd_) > 1e-4)
+    assert clear.sum() > 200 and np.array_equal(i[clear], ri[clear])
+    dup = (ri >= 60) & (ri < 160)                  # hits on the 100 copies: any of them is a correct winner
+    assert np.all((i[dup] >= 60) & (i[dup] < 160))
