@@ -848,6 +848,11 @@ __global__ void k_early_header(u64* __restrict__ hdr, const u64* __restrict__ cu
     }
 }
 
+__global__ void __launch_bounds__(kBlock) k_zero_words(u64* __restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) p[i] = 0ull;
+}
+
 // Dense copy of one plane's vertex-id records (the multi-GPU path ships the first plane to the previous rank, whose
 // halo plane it is).  After a one-pass call rec[] still holds region-form ids: translated here with the region
 // prefixes of the header.
@@ -1665,7 +1670,11 @@ int fused_stack_impl(const T* grids, const Dims& d, const Ws& w, float thresh, c
     u32 *csum = (u32*)(ws + w.chunk_sum), *woff = (u32*)(ws + w.wave_off);
     u64* cursors = (u64*)(ws + w.cur);
     u32* cpre = w.nchunks > kPreMinChunks ? (u32*)(ws + w.bbase_v) : nullptr;   // (see fused_impl)
-    HIP_TRY(hipMemsetAsync(cursors, 0, (size_t)d.nitems * kCursorBlockWords * sizeof(u64), st));
+    // (an ordinary kernel, not hipMemsetAsync: the runtime's fill path left the GPU idle for 11 us before it ran)
+    {
+        const int64_t nwords = (int64_t)d.nitems * kCursorBlockWords;
+        hipLaunchKernelGGL(k_zero_words, dim3((u32)((nwords + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, cursors, nwords);
+    }
     const u32 region_rows = 1u << 26;
     const u32 id_limit = (u32)std::min<int64_t>(region_rows, std::max(1, env_int("P3D_TEST_ID_LIMIT", 1 << 26)));
     const u32 store_rows =
@@ -1693,12 +1702,15 @@ int fused_stack_impl(const T* grids, const Dims& d, const Ws& w, float thresh, c
     const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows,
                          (nparts - early) * kRegions * d.nitems, early, nparts, 0, csum, (int)w.nchunks, cursors, id_limit,
                          d.nitems, item_offsets};
+    // per-item offsets and the totals for the host BEFORE the faces: everything they need (region cursors, chunk sums) is
+    // final after the counting launch, and the host then sizes its tensors and queues the next call while the faces are
+    // still being written (40 us of idle GPU per batch when this ran last)
+    hipLaunchKernelGGL(k_stack_finish, dim3(1), dim3(1024), 0, st, cursors, csum, (int)w.nchunks, d.nitems,
+                       scratch ? store_rows : region_rows, id_limit, item_offsets, hdr, mb, seq);
     {
         StageTimer tm(ST_EMIT_FACES, st);
         launch_faces(d, w, bits, rec, a, cp, hdr, faces, capf, w.nb_f > 0 && capf > 0, st);
     }
-    hipLaunchKernelGGL(k_stack_finish, dim3(1), dim3(1024), 0, st, cursors, csum, (int)w.nchunks, d.nitems,
-                       scratch ? store_rows : region_rows, id_limit, item_offsets, hdr, mb, seq);
     HIP_TRY(hipGetLastError());
     return P3D_OK;
 }
