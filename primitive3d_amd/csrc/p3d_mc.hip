@@ -1602,7 +1602,9 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         if (int rc = cursor_block_for(st, true, &cursors, &zero_next)) return rc;
     } else {
         cursors = hdr + H_CURSORS;
-        if (new_block) HIP_TRY(hipMemsetAsync(cursors, 0, (size_t)kCursorBlockWords * sizeof(u64), st));
+        if (new_block)   // (an ordinary kernel: the runtime's fill path starts late, see fused_stack_impl)
+            hipLaunchKernelGGL(k_zero_words, dim3((kCursorBlockWords + kBlock - 1) / kBlock), dim3(kBlock), 0, st, cursors,
+                               (int64_t)kCursorBlockWords);
     }
     if (part < 4) {
         const int stage = part == 1 ? ST_FUSED_INTERIOR : ST_FUSED;
