@@ -13,9 +13,10 @@
  *     vertex ids, and the tet index of every face (:226-234).
  *
  * Conventions: all pointers are DEVICE pointers owned by the caller (row-major, contiguous); `stream` is a hipStream_t
- * passed as void*; return 0 / negative P3D_MT_E*; p3d_mt_last_error() gives a thread-local message.  The two calls
- * below synchronise the stream where the reference's own ops do (boolean-mask indexing, torch.unique): the number of
- * active tets and the output sizes have to reach the host.
+ * passed as void*; return 0 / negative P3D_MT_E*; p3d_mt_last_error() gives a thread-local message.  p3d_mt_prepare
+ * waits for the device twice, where the reference's own ops synchronise (boolean-mask indexing, torch.unique): the
+ * number of active tets and the output sizes have to reach the host (through a pinned host slot the kernels write;
+ * P3D_NO_MAILBOX=1 or any failure: copy + hipStreamSynchronize).
  */
 #ifndef P3D_MT_H_
 #define P3D_MT_H_

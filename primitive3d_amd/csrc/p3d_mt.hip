@@ -22,10 +22,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <unordered_map>
 #include <rocprim/rocprim.hpp>
@@ -227,8 +229,26 @@ struct Sizes {   // what phase 1 found; kept in the last 64 bytes of the workspa
 };
 constexpr size_t kSizesOffset = 192;
 
+// Sizes reach the host through a slot of pinned, host-coherent memory that the kernel which learns them writes
+// (payload, then the call's sequence number with a system-scope release) and the host polls -- instead of a device-to-host
+// copy plus a stream synchronisation (each costs the call ~15 us more).  Any failure falls back to copy + synchronise.
+constexpr int kMtSlots = 64, kMtSlotWords = 8;
+
+__device__ inline void mt_report(u64* mb, u64 seq, u64 a, u64 b, u64 c) {
+    if (!mb) return;
+    mb[1] = a;
+    mb[2] = b;
+    mb[3] = c;
+    __threadfence_system();
+    __hip_atomic_store(&mb[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void k_mt_report_nvalid(const u32* __restrict__ last_inclusive, u64* mb, u64 seq) {
+    mt_report(mb, seq, (u64)*last_inclusive, 0ull, 0ull);
+}
+
 __global__ void k_mt_totals(const u64* __restrict__ nuniq, const u64* __restrict__ tcount, const u64* __restrict__ tscan,
-                            int64_t nv, int64_t nt, int64_t nvalid, u64* __restrict__ hdr) {
+                            int64_t nv, int64_t nt, int64_t nvalid, u64* __restrict__ hdr, u64* mb, u64 seq) {
     const u64 v = nvalid > 0 ? *nuniq : 0ull;
     const u64 both = nvalid > 0 ? tscan[nvalid - 1] + tcount[nvalid - 1] : 0ull;
     hdr[M_V] = v;
@@ -236,6 +256,7 @@ __global__ void k_mt_totals(const u64* __restrict__ nuniq, const u64* __restrict
     hdr[M_N2] = both >> 32;
     Sizes* sz = (Sizes*)((char*)hdr + kSizesOffset);
     *sz = Sizes{nv, nt, nvalid, (int64_t)v, (int64_t)(both & 0xffffffffull), (int64_t)(both >> 32)};
+    mt_report(mb, seq, v, both & 0xffffffffull, both >> 32);
 }
 
 __global__ void __launch_bounds__(kBlock) k_mt_vertices(const u64* __restrict__ sorted, int64_t nkeys, unsigned hb,
@@ -349,6 +370,55 @@ struct SizesCache {
 };
 SizesCache g_sizes;
 
+struct MtMailbox {
+    u64 *host = nullptr, *dev = nullptr;
+    bool failed = false;
+    u64 next_seq = 1;
+};
+std::mutex g_mtmb_mu;
+MtMailbox g_mtmb[64];
+
+// a slot for one report: its device pointer (null = unavailable), its host view and the sequence number to wait for
+u64* mt_mailbox_take(volatile u64** host_slot, u64* seq) {
+    static const bool disabled = getenv("P3D_NO_MAILBOX") != nullptr && atoi(getenv("P3D_NO_MAILBOX")) != 0;
+    int dev = 0;
+    if (disabled || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(g_mtmb_mu);
+    MtMailbox& m = g_mtmb[dev];
+    if (m.failed) return nullptr;
+    if (!m.host) {
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, (size_t)kMtSlots * kMtSlotWords * 8,
+                          hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess ||
+            hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            m.failed = true;
+            return nullptr;
+        }
+        memset(h, 0, (size_t)kMtSlots * kMtSlotWords * 8);
+        m.host = (u64*)h;
+        m.dev = (u64*)d;
+    }
+    *seq = m.next_seq++;
+    const size_t off = (size_t)(*seq % kMtSlots) * kMtSlotWords;
+    *host_slot = m.host + off;
+    return m.dev + off;
+}
+
+// polls the slot; false = recycled by a much newer call or timed out (the caller then copies + synchronises)
+bool mt_mailbox_wait(volatile u64* slot, u64 seq, u64 out[3]) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spin = 0;; ++spin) {
+        const u64 sv = __atomic_load_n(&slot[0], __ATOMIC_ACQUIRE);
+        if (sv == seq) break;
+        if (sv > seq) return false;
+        if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return false;
+        __builtin_ia32_pause();
+    }
+    for (int i = 0; i < 3; ++i) out[i] = __atomic_load_n(&slot[1 + i], __ATOMIC_ACQUIRE);
+    return __atomic_load_n(&slot[0], __ATOMIC_ACQUIRE) == seq;   // (seqlock: not recycled while the payload was read)
+}
+
 inline unsigned index_bits(int64_t nv) {   // bits of a point index (>= 1)
     unsigned hb = 1;
     while (hb < 32 && (1ull << hb) < (u64)nv) ++hb;
@@ -400,10 +470,19 @@ int p3d_mt_prepare(const float* vertices, int64_t num_vertices, int64_t* tets, i
                                num_tets, (const u32*)occ, cas, wmask, wcnt);
         // inclusive: its last element is the number of active tets (a wave's first slot = its element - its count)
         HIP_TRY(rocprim::inclusive_scan(temp, tb, wcnt, wbase, (size_t)nw, rocprim::plus<u32>(), st));
-        u32 nvalid = 0;
-        HIP_TRY(hipMemcpyAsync(&nvalid, wbase + (nw - 1), sizeof(u32), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));   // (the reference synchronises here too: tets[valid_tets], :157)
-        sz.nvalid = (int64_t)nvalid;
+        // (the reference synchronises here too: tets[valid_tets], :157)
+        volatile u64* slot = nullptr;
+        u64 seq = 0, got[3];
+        u64* mb = mt_mailbox_take(&slot, &seq);
+        if (mb) hipLaunchKernelGGL(k_mt_report_nvalid, dim3(1), dim3(1), 0, st, wbase + (nw - 1), mb, seq);
+        if (mb && mt_mailbox_wait(slot, seq, got)) {
+            sz.nvalid = (int64_t)got[0];
+        } else {
+            u32 nvalid = 0;
+            HIP_TRY(hipMemcpyAsync(&nvalid, wbase + (nw - 1), sizeof(u32), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            sz.nvalid = (int64_t)nvalid;
+        }
     }
     if (sz.nvalid > 0) {
         const size_t slots = table_slots(sz.nvalid);
@@ -416,14 +495,24 @@ int p3d_mt_prepare(const float* vertices, int64_t num_vertices, int64_t* tets, i
         HIP_TRY(rocprim::exclusive_scan(temp, tb, tcount, tscan, 0ull, (size_t)sz.nvalid, rocprim::plus<u64>(), st));
     }
     // totals, and the sizes for p3d_mt_emit in the workspace header (written by the device: no upload, no wait)
-    hipLaunchKernelGGL(k_mt_totals, dim3(1), dim3(1), 0, st, hdr + M_V, tcount, tscan, num_vertices, num_tets, sz.nvalid, hdr);
+    volatile u64* slot2 = nullptr;
+    u64 seq2 = 0, got2[3];
+    u64* mb2 = sz.nvalid > 0 ? mt_mailbox_take(&slot2, &seq2) : nullptr;
+    hipLaunchKernelGGL(k_mt_totals, dim3(1), dim3(1), 0, st, hdr + M_V, tcount, tscan, num_vertices, num_tets, sz.nvalid, hdr,
+                       mb2, seq2);
     if (sz.nvalid > 0) {
-        u64 h[4] = {0, 0, 0, 0};
-        HIP_TRY(hipMemcpyAsync(h, hdr, sizeof(h), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        sz.nv_out = (int64_t)h[M_V];
-        sz.n1 = (int64_t)h[M_N1];
-        sz.n2 = (int64_t)h[M_N2];
+        if (mb2 && mt_mailbox_wait(slot2, seq2, got2)) {
+            sz.nv_out = (int64_t)got2[0];
+            sz.n1 = (int64_t)got2[1];
+            sz.n2 = (int64_t)got2[2];
+        } else {
+            u64 h[4] = {0, 0, 0, 0};
+            HIP_TRY(hipMemcpyAsync(h, hdr, sizeof(h), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            sz.nv_out = (int64_t)h[M_V];
+            sz.n1 = (int64_t)h[M_N1];
+            sz.n2 = (int64_t)h[M_N2];
+        }
     }
     HIP_TRY(hipGetLastError());
     g_sizes.put(ws_, sz);
