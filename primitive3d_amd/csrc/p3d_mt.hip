@@ -130,8 +130,10 @@ struct P3 {
 
 __device__ inline u32 occ_bit(const u32* __restrict__ occ, u64 i) { return (occ[i >> 5] >> (i & 31u)) & 1u; }
 
-__global__ void __launch_bounds__(kBlock) k_mt_occ(const float* __restrict__ sdf, int64_t nv, u64* __restrict__ occ) {
+__global__ void __launch_bounds__(kBlock) k_mt_occ(const float* __restrict__ sdf, int64_t nv, u64* __restrict__ occ,
+                                                    u64* __restrict__ hdr) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < 32) hdr[i] = 0ull;   // the 256-byte header (ordinary kernels instead of the runtime's fill path, which starts late)
     const u64 m = __ballot(i < nv && sdf[i < nv ? i : 0] > 0.f);   // :151
     if ((threadIdx.x & 63) == 0) occ[i >> 6] = m;
 }
@@ -181,6 +183,11 @@ __global__ void __launch_bounds__(kBlock) k_mt_classify(const float* __restrict_
         wmask[t >> 6] = m;
         wcnt[t >> 6] = (u32)__popcll(m);
     }
+}
+
+__global__ void __launch_bounds__(kBlock) k_mt_fill_empty(ulonglong2* __restrict__ table, size_t n2) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (size_t)gridDim.x * kBlock)
+        table[i] = ulonglong2{kEmpty, kEmpty};
 }
 
 __device__ inline u64 mix64(u64 k) {
@@ -458,10 +465,10 @@ int p3d_mt_prepare(const float* vertices, int64_t num_vertices, int64_t* tets, i
     size_t tb = w.temp_bytes;
     const unsigned hb = index_bits(num_vertices);
     Sizes sz{num_vertices, num_tets, 0, 0, 0, 0};
-    HIP_TRY(hipMemsetAsync(hdr, 0, 256, st));
+    if (num_tets <= 0) HIP_TRY(hipMemsetAsync(hdr, 0, 256, st));
     if (num_tets > 0) {
         const int64_t nw = (num_tets + 63) / 64;
-        hipLaunchKernelGGL(k_mt_occ, dim3(blocks_for(num_vertices)), dim3(kBlock), 0, st, sdf, num_vertices, occ);
+        hipLaunchKernelGGL(k_mt_occ, dim3(blocks_for(num_vertices)), dim3(kBlock), 0, st, sdf, num_vertices, occ, hdr);
         if (((uintptr_t)tets & 15u) == 0)
             hipLaunchKernelGGL((k_mt_classify<true>), dim3(blocks_for(num_tets)), dim3(kBlock), 0, st, vertices, tets, num_tets,
                                (const u32*)occ, cas, wmask, wcnt);
@@ -486,7 +493,8 @@ int p3d_mt_prepare(const float* vertices, int64_t num_vertices, int64_t* tets, i
     }
     if (sz.nvalid > 0) {
         const size_t slots = table_slots(sz.nvalid);
-        HIP_TRY(hipMemsetAsync(table, 0xff, slots * sizeof(u64), st));
+        hipLaunchKernelGGL(k_mt_fill_empty, dim3((u32)std::min<size_t>(slots / 2 / kBlock, 4096)), dim3(kBlock), 0, st,
+                           (ulonglong2*)table, slots / 2);
         hipLaunchKernelGGL(k_mt_edges, dim3(blocks_for(num_tets)), dim3(kBlock), 0, st, tets, num_tets, cas, wmask, wbase,
                            vlist, table, (u64)(slots - 1), tcount, hb);
         tb = w.temp_bytes;
