@@ -13,8 +13,8 @@
 //   (select)        the distinct keys out of the hash table
 //   (radix sort)    of the distinct keys only (V of them, not 6 per active tet): ascending = their order among
 //                   torch.unique's lexicographically sorted rows (:160), so the rank of a key IS its vertex id (:165-170)
-//   k_mt_vertices   interpolation with the reference's float32 operation order (:178-190), one thread per sorted key
-//   k_mt_ranks      every sorted key leaves its rank (= vertex id) at its slot of the hash table
+//   k_mt_vertices   one thread per sorted key: interpolation with the reference's float32 operation order (:178-190);
+//                   the key's rank (= vertex id) is left at its slot of the hash table
 //   k_mt_faces      triangles by the 16-case table, one-triangle tets first (:205-224), tet index per face (:226-234);
 //                   8 lanes per tet: six look up the ids of its edges (one probe each), the corners pick by shuffle
 //
@@ -266,12 +266,24 @@ __global__ void k_mt_totals(const u64* __restrict__ nuniq, const u64* __restrict
     mt_report(mb, seq, v, both & 0xffffffffull, both >> 32);
 }
 
+// slot of a key that IS in the hash set
+__device__ inline u64 find_slot(const u64* __restrict__ table, u64 table_mask, u64 key) {
+    u64 h = mix64(key) & table_mask;
+    while (table[h] != key) h = (h + 1) & table_mask;
+    return h;
+}
+
+// one thread per sorted key: its rank IS the vertex id (:165-171) -- left at the key's hash slot, where the faces find
+// it -- and the interpolated position
 __global__ void __launch_bounds__(kBlock) k_mt_vertices(const u64* __restrict__ sorted, int64_t nkeys, unsigned hb,
                                                         const float* __restrict__ vertices, const float* __restrict__ sdf,
-                                                        float* __restrict__ out, int64_t* __restrict__ pairs) {
+                                                        const u64* __restrict__ table, u64 table_mask,
+                                                        u32* __restrict__ rank, float* __restrict__ out,
+                                                        int64_t* __restrict__ pairs) {
     const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (v >= nkeys) return;
     const u64 k = sorted[v];
+    rank[find_slot(table, table_mask, k)] = (u32)v;
     const int64_t a = (int64_t)(k >> hb), b = (int64_t)(k & ((1ull << hb) - 1ull));
     // :178-190, operation for operation in float32: [s_a, -s_b], their sum, the flipped pair divided by it, then
     // p_a * w0 + p_b * w1 (build flag -ffp-contract=off keeps the products and the sum separately rounded)
@@ -285,21 +297,6 @@ __global__ void __launch_bounds__(kBlock) k_mt_vertices(const u64* __restrict__ 
         pairs[v * 2] = a;
         pairs[v * 2 + 1] = b;
     }
-}
-
-// slot of a key that IS in the hash set
-__device__ inline u64 find_slot(const u64* __restrict__ table, u64 table_mask, u64 key) {
-    u64 h = mix64(key) & table_mask;
-    while (table[h] != key) h = (h + 1) & table_mask;
-    return h;
-}
-
-// vertex id of every distinct crossing edge = its rank among the sorted keys (:165-171), left where the faces find it
-__global__ void __launch_bounds__(kBlock) k_mt_ranks(const u64* __restrict__ sorted, int64_t nkeys,
-                                                     const u64* __restrict__ table, u64 table_mask, u32* __restrict__ rank) {
-    const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (v >= nkeys) return;
-    rank[find_slot(table, table_mask, sorted[v])] = (u32)v;
 }
 
 // 8 lanes per active tet: lane e < 6 looks up edge e's vertex id, lane k < 3n writes corner k of the tet's triangles
@@ -552,9 +549,7 @@ int p3d_mt_emit(const float* vertices, const int64_t* tets, const float* sdf, vo
         size_t tb = w.temp_bytes;
         HIP_TRY(rocprim::radix_sort_keys<SortConfig>(ws + w.temp, tb, uniq, sorted, (size_t)sz.nv_out, 0u, 2u * hb, st));
         hipLaunchKernelGGL(k_mt_vertices, dim3(blocks_for(sz.nv_out)), dim3(kBlock), 0, st, (const u64*)sorted, sz.nv_out, hb,
-                           vertices, sdf, out_vertices, out_edge_pairs);
-        hipLaunchKernelGGL(k_mt_ranks, dim3(blocks_for(sz.nv_out)), dim3(kBlock), 0, st, (const u64*)sorted, sz.nv_out, table,
-                           table_mask, rank);
+                           vertices, sdf, table, table_mask, rank, out_vertices, out_edge_pairs);
     }
     if (sz.n1 + sz.n2 > 0)
         hipLaunchKernelGGL(k_mt_faces, dim3(blocks_for(sz.nvalid * 8)), dim3(kBlock), 0, st, tets, (const u32*)(ws + w.vlist),
