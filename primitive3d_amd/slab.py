@@ -352,6 +352,9 @@ class SlabExtractor:
             self._mark("last planes streamed + record export")
             pre_comm()
             dist.all_gather_into_tensor(rank_counts, be.header_vertex_count())
+            counts_ready = torch.cuda.Event() if self.grid.is_cuda else None
+            if counts_ready is not None:
+                counts_ready.record()
             self._mark("all-gather of vertex counts")
             rec_works = shift_to_prev(send_buf, self.records_recv_buffer())
             be.launch_finalize()
@@ -365,12 +368,20 @@ class SlabExtractor:
             # int32 guard on the GLOBAL vertex total (the host path checks it in phase_faces): the gathered counts live
             # on the device, so they are copied to pinned memory behind the work already enqueued and looked at when the
             # next extraction starts or when the caller asks (SlabResult.check_total) -- never a wait inside this call
+            # (on a side stream, ordered only after the all-gather: inside the compute stream the 64-byte copy cost the
+            #  stream ~10 us per extraction)
             self._check_pending_total()
             host = torch.empty(self.world, dtype=torch.int64, pin_memory=True) if self.grid.is_cuda else None
             if host is not None:
-                host.copy_(rank_counts, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
+                if getattr(self, "_guard_stream", None) is None:
+                    self._guard_stream = torch.cuda.Stream(device=self.grid.device)
+                gs = self._guard_stream
+                gs.wait_event(counts_ready)
+                with torch.cuda.stream(gs):
+                    host.copy_(rank_counts, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(gs)
+                rank_counts.record_stream(gs)
                 self._pending_total = (host, ev)
             return SlabResult(self._verts, faces, rank=self.rank, rank_counts=rank_counts,
                               check=self._check_pending_total)
