@@ -1470,15 +1470,17 @@ template <typename T, int NC, int RY>
 void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xform& t, int64_t x_origin, u64* bits,
                   uint2* rec, u64* cursors, u64* zero_next, float* scratch, u32 region_rows, u32 store_rows, int x_lo,
                   int x_hi,
-                  hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
+                  hipEvent_t ev0, hipEvent_t ev1, hipStream_t st, int cz_base = 0, int cz_count = -1) {
     FusedGeom g;
     g.x_lo = x_lo;
     g.x_hi = x_hi;
     g.nxt_item = 0;
+    g.cz_base = cz_base;   // chunks [cz_base, cz_base + cz_count) of every row (default: the whole row)
+    if (cz_count < 0) cz_count = (int)d.ncz - cz_base;
     const bool stack = d.stack != 0;   // a batch of grids: every x-slab lies inside one item, all items in one launch
     const int64_t nplanes = stack ? d.xper : x_hi - x_lo;
     if (nplanes <= 0) return;
-    g.nzt = (d.ncz + NC - 1) / NC;
+    g.nzt = (cz_count + NC - 1) / NC;
     g.nyt = (int)((d.ry + kFusedWPB * RY - 1) / (kFusedWPB * RY));
     // planes per block: enough blocks to fill the chip a few times over, but >= 8 planes (x-halo overhead 1/XT)
     // unless the grid is so small that 8-plane blocks would leave most CUs idle (then latency wins over the halo)
@@ -1516,7 +1518,7 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
     }
     const int64_t nblocks = per_slab * g.nxt;
     // (the timing events, if any, ride on the dispatch packet itself: no extra barrier packets around the kernel)
-    if (ev0)
+    if (ev0 || ev1)   // (rows split over two launches: the first carries the start event, the second the stop event)
         hipExtLaunchKernelGGL((k_fused<T, NC, RY>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, ev0, ev1, 0, grid, thresh,
                               d, g, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows, store_rows);
     else
@@ -1532,6 +1534,18 @@ void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const 
     // tile geometries (32 unit words per wave-plane unless noted): long rows (8 chunks x 3 rows per wave), rows of 3-4
     // chunks (rz <= 256: 4 chunks x 7 rows -- the 8-chunk tile would be half empty -- or, for a single small grid,
     // 16-unit tiles of 4 chunks x 3 rows), short rows (2 chunks x 15 rows)
+    const int rem = (int)(d.ncz % 8);
+    if (d.ncz >= 9 && rem >= 1 && rem <= 2 && env_int("P3D_FUSED_SPLIT_ROWS", 1)) {
+        // rows of 8k + 1..2 chunks (rz = 513, 517, 600, 1025: grids of 2^n + 1 samples are common): the 8-chunk tiles take
+        // the first 8k chunks, a second launch with the 2-chunk tile the rest -- a last 8-chunk tile would be 1/8 or 1/4
+        // full (513 x 511 x 517: 169 -> 155 us; with 3..4 chunks left over the split measured no gain)
+        const int full = (int)d.ncz - rem;
+        launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                              store_rows, x_lo, x_hi, ev0, nullptr, st, 0, full);
+        launch_fused<T, 2, 15>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                               store_rows, x_lo, x_hi, nullptr, ev1, st, full, rem);
+        return;
+    }
     if (d.ncz >= 5)
         launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
                               store_rows, x_lo, x_hi, ev0, ev1, st);

@@ -11,7 +11,7 @@ rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
 gpu = torch.device("cuda", 0)
 for it in range(int(os.environ.get("N", "25"))):
     world = int(rng.integers(2, 5))
-    rx = int(rng.integers(world, 90)); ry = int(rng.integers(2, 30)); rz = int(rng.choice([rng.integers(2, 70), rng.integers(100, 300)]))
+    rx = int(rng.integers(world, 90)); ry = int(rng.integers(2, 30)); rz = int(rng.choice([rng.integers(2, 70), rng.integers(100, 300), rng.integers(513, 650)]))
     x, y, z = np.meshgrid(np.arange(rx), np.arange(ry), np.arange(rz), indexing="ij")
     g = (np.sin(x * 0.45) + np.cos(y * 0.5) + np.sin(z * 0.21) + 0.2 * rng.standard_normal((rx, ry, rz))).astype(np.float32)
     thresh, lower, upper = float(rng.uniform(-0.3, 0.3)), [0.5, -1.0, 2.0], [3.0, 4.0, 9.0]
