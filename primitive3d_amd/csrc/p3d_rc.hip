@@ -16,7 +16,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <limits>
+#include <memory>
+#include <thread>
 #include <vector>
 
 #include "../../include/p3d_rc.h"
@@ -53,12 +56,41 @@ int fail(int code, const char* fmt, const char* detail = "") {
         if (e_ != hipSuccess) return fail(P3D_RC_EHIP, #expr ": %s", hipGetErrorString(e_)); \
     } while (0)
 
+// chunks [0, n) over up to 16 host threads (small n: the calling thread alone)
+template <class F>
+void parallel_chunks(size_t n, F&& fn) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nt = n < 65536 ? 1 : std::min<size_t>(16, std::max(1u, hw));
+    if (nt <= 1) {
+        fn((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t per = (n + nt - 1) / nt;
+    for (size_t t = 1; t < nt; ++t) th.emplace_back([&, t] { fn(std::min(n, t * per), std::min(n, (t + 1) * per)); });
+    fn((size_t)0, std::min(n, per));
+    for (auto& x : th) x.join();
+}
+
 // ---- host: 4-ary build (bvh.cu:209-300: two rounds of median splits on the axis of largest centroid variance) ----------
+// The subtrees of the first two levels (up to 16) are built by their own host threads: the triangle ranges are disjoint,
+// nodes come out of one preallocated array through an atomic counter (the reference builds on one thread).
 struct Builder {
     std::vector<HostTri>& tris;
-    std::vector<Node> nodes;
-    int max_depth = 0;
-    explicit Builder(std::vector<HostTri>& t) : tris(t) {}
+    std::unique_ptr<Node[]> nodes;     // preallocated (not zero-filled); `used` of them are taken
+    size_t cap = 0;
+    std::atomic<int32_t> used{0};
+    std::atomic<int> max_depth{0};
+    std::atomic<bool> overflow{false};
+    int par_levels = 0;                // levels whose children are built concurrently
+    explicit Builder(std::vector<HostTri>& t) : tris(t) {
+        // inner nodes I(n) <= n / 3 - 1 for n >= 9 triangles (induction over the four children, each of which holds at
+        // least two triangles); the balanced median splits produce about 0.15 n
+        cap = t.size() / 3 + 16;
+        nodes.reset(new Node[cap]);
+        const unsigned hw = std::thread::hardware_concurrency();
+        par_levels = (t.size() >= 65536 && hw >= 4) ? (hw >= 16 ? 2 : 1) : 0;
+    }
 
     void bounds(size_t b, size_t e, float lo[3], float hi[3]) const {
         for (int k = 0; k < 3; ++k) {
@@ -90,34 +122,54 @@ struct Builder {
     }
     // returns the link of the subtree over [b, e)
     int32_t build(size_t b, size_t e, int depth) {
-        max_depth = std::max(max_depth, depth);
+        int seen = max_depth.load();
+        while (depth > seen && !max_depth.compare_exchange_weak(seen, depth)) {}
         if (e - b <= (size_t)kLeafTris) return -(int32_t)(b * 16 + (e - b)) - 1;
-        const int32_t me = (int32_t)nodes.size();
-        nodes.emplace_back();
+        const int32_t me = used.fetch_add(1);
+        if ((size_t)me >= cap) {   // (cannot happen with the bound above; reported, never written past the array)
+            overflow = true;
+            return INT32_MIN;
+        }
         size_t cut[5];
         cut[0] = b;
         cut[4] = e;
         cut[2] = split(b, e);
-        cut[1] = split(cut[0], cut[2]);
-        cut[3] = split(cut[2], cut[4]);
-        for (int k = 0; k < 4; ++k) {
+        if (depth < par_levels) {   // the two halves are independent
+            std::thread t([&] { cut[1] = split(cut[0], cut[2]); });
+            cut[3] = split(cut[2], cut[4]);
+            t.join();
+        } else {
+            cut[1] = split(cut[0], cut[2]);
+            cut[3] = split(cut[2], cut[4]);
+        }
+        int32_t link[4];
+        auto child = [&](int k) {
             float lo[3], hi[3];
-            int32_t link = INT32_MIN;
+            link[k] = INT32_MIN;
             if (cut[k + 1] > cut[k]) {
                 bounds(cut[k], cut[k + 1], lo, hi);
-                link = build(cut[k], cut[k + 1], depth + 1);
+                link[k] = build(cut[k], cut[k + 1], depth + 1);
             } else {
                 for (int a = 0; a < 3; ++a) {
                     lo[a] = std::numeric_limits<float>::infinity();
                     hi[a] = -std::numeric_limits<float>::infinity();
                 }
             }
-            Node& nd = nodes[me];   // (re-fetched: the vector may have grown)
+            Node& nd = nodes[me];   // (child k writes column k only)
             for (int a = 0; a < 3; ++a) {
                 nd.lo[a][k] = lo[a];
                 nd.hi[a][k] = hi[a];
             }
-            nd.child[k] = link;
+            nd.child[k] = link[k];
+            nd.pad[k] = 0;
+        };
+        if (depth < par_levels) {
+            std::thread th[3];
+            for (int k = 0; k < 3; ++k) th[k] = std::thread(child, k);
+            child(3);
+            for (int k = 0; k < 3; ++k) th[k].join();
+        } else {
+            for (int k = 0; k < 4; ++k) child(k);
         }
         return me;
     }
@@ -255,48 +307,58 @@ int p3d_rc_create(const float* vertices, int64_t num_vertices, const int32_t* fa
     if (num_faces < 1 || num_vertices < 1) return fail(P3D_RC_EINVAL, "need at least one triangle%s");
     if (num_faces >= (1ll << 27)) return fail(P3D_RC_ERANGE, "more than 2^27 triangles%s");
     std::vector<HostTri> tris((size_t)num_faces);
-    for (int64_t f = 0; f < num_faces; ++f) {
-        HostTri& t = tris[(size_t)f];
-        const int32_t ia = faces[f * 3], ib = faces[f * 3 + 1], ic = faces[f * 3 + 2];
-        if (ia < 0 || ib < 0 || ic < 0 || ia >= num_vertices || ib >= num_vertices || ic >= num_vertices)
-            return fail(P3D_RC_EINVAL, "face index out of range%s");
-        for (int k = 0; k < 3; ++k) {
-            t.a[k] = vertices[(size_t)ia * 3 + k];
-            t.b[k] = vertices[(size_t)ib * 3 + k];
-            t.c[k] = vertices[(size_t)ic * 3 + k];
-            t.cen[k] = (t.a[k] + t.b[k] + t.c[k]) / 3.0f;   // triangle.h:40-46
-            if (!(t.cen[k] == t.cen[k])) t.cen[k] = 0.0f;   // NaN coordinates: keep the split comparator a strict weak order
+    std::atomic<bool> bad{false};
+    parallel_chunks((size_t)num_faces, [&](size_t f0, size_t f1) {
+        for (size_t f = f0; f < f1; ++f) {
+            HostTri& t = tris[f];
+            const int32_t ia = faces[f * 3], ib = faces[f * 3 + 1], ic = faces[f * 3 + 2];
+            if (ia < 0 || ib < 0 || ic < 0 || ia >= num_vertices || ib >= num_vertices || ic >= num_vertices) {
+                bad = true;
+                return;
+            }
+            for (int k = 0; k < 3; ++k) {
+                t.a[k] = vertices[(size_t)ia * 3 + k];
+                t.b[k] = vertices[(size_t)ib * 3 + k];
+                t.c[k] = vertices[(size_t)ic * 3 + k];
+                t.cen[k] = (t.a[k] + t.b[k] + t.c[k]) / 3.0f;   // triangle.h:40-46
+                if (!(t.cen[k] == t.cen[k])) t.cen[k] = 0.0f;   // NaN coordinates: keep the split comparator a strict weak order
+            }
+            t.idx = (int32_t)f;
         }
-        t.idx = (int32_t)f;
-    }
+    });
+    if (bad) return fail(P3D_RC_EINVAL, "face index out of range%s");
     Builder bld(tris);
-    bld.nodes.reserve((size_t)num_faces / 4 + 16);
     const int32_t root = bld.build(0, tris.size(), 0);
-    if (3 * bld.max_depth + 1 > kStackMax) return fail(P3D_RC_ERANGE, "tree deeper than the traversal stack%s");
-    std::vector<float4> packed(tris.size() * 3);
-    for (size_t i = 0; i < tris.size(); ++i) {
-        float w;
-        memcpy(&w, &tris[i].idx, 4);
-        packed[i * 3] = make_float4(tris[i].a[0], tris[i].a[1], tris[i].a[2], w);
-        packed[i * 3 + 1] = make_float4(tris[i].b[0], tris[i].b[1], tris[i].b[2], 0.f);
-        packed[i * 3 + 2] = make_float4(tris[i].c[0], tris[i].c[1], tris[i].c[2], 0.f);
-    }
+    if (bld.overflow) return fail(P3D_RC_ERANGE, "node array too small%s");
+    const size_t num_nodes = (size_t)bld.used.load();
+    if (3 * bld.max_depth.load() + 1 > kStackMax) return fail(P3D_RC_ERANGE, "tree deeper than the traversal stack%s");
+    std::unique_ptr<float4[]> packed(new float4[tris.size() * 3]);
+    const size_t packed_n = tris.size() * 3;
+    parallel_chunks(tris.size(), [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; ++i) {
+            float w;
+            memcpy(&w, &tris[i].idx, 4);
+            packed[i * 3] = make_float4(tris[i].a[0], tris[i].a[1], tris[i].a[2], w);
+            packed[i * 3 + 1] = make_float4(tris[i].b[0], tris[i].b[1], tris[i].b[2], 0.f);
+            packed[i * 3 + 2] = make_float4(tris[i].c[0], tris[i].c[1], tris[i].c[2], 0.f);
+        }
+    });
     p3d_rc_caster* c = new p3d_rc_caster();
-    c->num_nodes = (int64_t)bld.nodes.size();
+    c->num_nodes = (int64_t)num_nodes;
     c->num_tris = num_faces;
     c->root = root;
-    c->max_depth = bld.max_depth;
+    c->max_depth = bld.max_depth.load();
     if (hipGetDevice(&c->device) != hipSuccess) {
         delete c;
         return fail(P3D_RC_EHIP, "hipGetDevice failed%s");
     }
-    const size_t nb = std::max<size_t>(bld.nodes.size(), 1) * sizeof(Node);
-    if (hipMalloc((void**)&c->nodes, nb) != hipSuccess || hipMalloc((void**)&c->tris, packed.size() * sizeof(float4)) != hipSuccess) {
+    const size_t nb = std::max<size_t>(num_nodes, 1) * sizeof(Node);
+    if (hipMalloc((void**)&c->nodes, nb) != hipSuccess || hipMalloc((void**)&c->tris, packed_n * sizeof(float4)) != hipSuccess) {
         p3d_rc_destroy(c);
         return fail(P3D_RC_EHIP, "hipMalloc failed%s");
     }
-    if ((!bld.nodes.empty() && hipMemcpy(c->nodes, bld.nodes.data(), bld.nodes.size() * sizeof(Node), hipMemcpyHostToDevice) != hipSuccess) ||
-        hipMemcpy(c->tris, packed.data(), packed.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess) {
+    if ((num_nodes > 0 && hipMemcpy(c->nodes, bld.nodes.get(), num_nodes * sizeof(Node), hipMemcpyHostToDevice) != hipSuccess) ||
+        hipMemcpy(c->tris, packed.get(), packed_n * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess) {
         p3d_rc_destroy(c);
         return fail(P3D_RC_EHIP, "hipMemcpy failed%s");
     }
