@@ -281,3 +281,41 @@ def test_adapter_modes_in_a_fresh_process(gpu, env):
         assert got[2:] == [nv, nf], got
     else:     # default: rows [0, V) of a buffer that may be up to 1/8 + 4096 rows longer
         assert nv <= got[2] <= nv + nv // 8 + 4096 and nf <= got[3] <= nf + nf // 8 + 4096, got
+
+
+def test_threads_on_their_own_streams(gpu, built):
+    """Three host threads, each on its own stream, call the adapter concurrently on different grids (per-stream cursor
+    rings, per-call mailbox slots, the shape-hint map): every result equals the single-threaded result of its grid."""
+    import threading
+    from bench import soup_hashes
+    from primitive3d_amd.fields import perlin_grid
+    shapes = [(96, 80, 130), (64, 64, 64), (128, 128, 200), (40, 200, 520)]
+    grids = [perlin_grid(s, period=24, seed=i, device=gpu) for i, s in enumerate(shapes)]
+    ref = []
+    for g in grids:
+        v, f = built.marching_cubes(g, 0.0)
+        torch.cuda.synchronize()
+        ref.append((v.shape[0], f.shape[0], soup_hashes(v, f)[0]))
+    errors = []
+
+    def worker(tid):
+        st = torch.cuda.Stream(device=gpu)
+        with torch.cuda.stream(st):
+            for it in range(40):
+                k = (it * 3 + tid) % len(grids)
+                v, f = built.marching_cubes(grids[k], 0.0)
+                if (v.shape[0], f.shape[0]) != ref[k][:2]:
+                    errors.append((tid, it, k, tuple(v.shape), tuple(f.shape)))
+                elif it % 8 == 0:
+                    st.synchronize()
+                    if not torch.equal(soup_hashes(v, f)[0], ref[k][2]):
+                        errors.append((tid, it, k, "triangle soup differs"))
+        st.synchronize()
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors[:5]
