@@ -177,3 +177,35 @@ def test_special_sdf_values(gpu, built):
     assert np.array_equal(ti.cpu().numpy(), rti)
     assert np.array_equal(v.cpu().numpy(), rv, equal_nan=True)
     assert np.isnan(rv).any() and np.isfinite(rv).any()
+
+
+def test_threads_on_their_own_streams(gpu, built):
+    """Concurrent calls from three host threads, each on its own stream (pinned size slots, the host-side copy of the
+    sizes between the two phases): every result equals the single-threaded one."""
+    import threading
+    meshes = []
+    for n, seed in ((8, 1), (12, 2), (15, 3)):
+        P, T, sdf = _grid_tets(n, seed)
+        tets = torch.from_numpy(T.copy()).to(gpu)
+        args = (torch.from_numpy(P).to(gpu), tets, torch.from_numpy(sdf).to(gpu))
+        v, f = built.marching_tetrahedras(*args)   # (also orients the tets once)
+        torch.cuda.synchronize()
+        meshes.append((args, v.clone(), f.clone()))
+    errors = []
+
+    def worker(tid):
+        st = torch.cuda.Stream(device=gpu)
+        with torch.cuda.stream(st):
+            for it in range(30):
+                args, rv, rf = meshes[(it + tid) % len(meshes)]
+                v, f = built.marching_tetrahedras(*args)
+                st.synchronize()
+                if not (torch.equal(v, rv) and torch.equal(f, rf)):
+                    errors.append((tid, it))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
