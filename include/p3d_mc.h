@@ -16,6 +16,9 @@
  *     things of its own per device / stream: a ring of pre-cleared 4 KiB blocks for the streaming kernel's output
  *     cursors and a 4 KiB pinned host mailbox through which the kernels report totals.  No torch types cross
  *     this boundary.
+ *   - Threads: every entry point may be called concurrently from several host threads, on different streams or on
+ *     ONE stream (each call with its own workspace and output buffers); the launches of a whole-grid
+ *     p3d_mc_extract_fused are enqueued under a per-stream lock, so calls sharing a stream queue up whole.
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All calls enqueue work on
  *     it and return immediately; p3d_mc_read_counts waits for the totals only (see there), not for the stream.
  *   - Grid layout is the reference's: contiguous [rx][ry][rz], z fastest (marching_cubes.cu:20).
@@ -36,7 +39,7 @@
 extern "C" {
 #endif
 
-#define P3D_MC_ABI_VERSION 5
+#define P3D_MC_ABI_VERSION 6
 
 /* dtype of the scalar field */
 #define P3D_F32 0
@@ -186,6 +189,12 @@ int p3d_mc_export_plane_records(const void* ws, int64_t rx, int64_t ry, int64_t 
 int p3d_mc_profile_enable(int mode);
 int p3d_mc_profile_read(float* stage_ms, int n);
 const char* p3d_mc_profile_stage_name(int stage);
+
+/* Developer / test hook (no reference counterpart).  The launch-shape knobs of the developer sweeps and the two test
+ * hooks (P3D_FUSED_BLOCKS, P3D_FUSED_XT, P3D_FUSED_XT_TAIL, P3D_FUSED_TAIL_DIV, P3D_FUSED_SPLIT_ROWS,
+ * P3D_FUSED_SMALL16, P3D_COMPACT_BLOCKS, P3D_COMPACT_EARLY, P3D_TEST_ID_LIMIT, P3D_NO_CHUNK_PRE) are read from the environment ONCE, at
+ * the first call; this re-reads them.  Not to be called while another thread is inside the library. */
+int p3d_mc_reload_tuning(void);
 
 const char* p3d_last_error(void);
 int p3d_mc_abi_version(void);

@@ -6,7 +6,12 @@
  * active tetrahedra) by a handful of hand-written HIP kernels around a hash set of the CROSSING edges and one radix sort
  * of the distinct ones (only those become vertices).  Same results:
  *   - the orientation fix of :147-148 (tets with a negative [1,x,y,z] determinant get corners 0 and 1 swapped, IN
- *     PLACE in the caller's array, as the reference does),
+ *     PLACE in the caller's array, as the reference does).  The determinant is taken in float64 from the float32
+ *     coordinates; the reference's is a float32 LU (`torch.det`, :50-65).  The two signs can differ only where the
+ *     determinant is rounding noise: measured against reference-run vectors that keep their slivers
+ *     (tests/golden/tetraslivers_*.npz, ~1600 of 14.9 k tets with |det| < 1e-7): 0 tets at a point jitter of 1e-6, 6 of
+ *     14 847 at 3e-8, all with |det| < 1e-25; such a tet's triangles then have the opposite winding, nothing else
+ *     changes (tests/tetra_compare.py),
  *   - vertices in the order of torch.unique's sorted rows (:160-171), computed with the reference's float32 operation
  *     order (:178-190),
  *   - faces by the 16-case table (:8-29): all one-triangle tets first, then the two-triangle tets (:205-224), int64
@@ -28,18 +33,22 @@
 extern "C" {
 #endif
 
-#define P3D_MT_ABI_VERSION 1
+#define P3D_MT_ABI_VERSION 2
 #define P3D_MT_OK 0
 #define P3D_MT_EINVAL (-1)
 #define P3D_MT_ERANGE (-2)   /* more than 2^32 - 1 vertices, or more edges than 32-bit slots */
 #define P3D_MT_EHIP (-3)
+#define P3D_MT_EINDEX (-4)   /* a tet refers to a point outside [0, num_vertices): the reference's indexing raises IndexError */
 
-/* Device scratch for a mesh of num_tets tetrahedra (worst case: every tet active; about 160 bytes per tet). */
+/* Device scratch for a mesh of num_tets tetrahedra (worst case: every tet active; about 250 bytes per tet: the hash set
+ * of edges and its rank table 36 B, the distinct keys and their sorted copy 64 B, rocPRIM's temporaries, per-tet lists). */
 int p3d_mt_workspace_bytes(int64_t num_vertices, int64_t num_tets, size_t* bytes);
 
 /* Phase 1: orientation fix (tets is IN/OUT), classification of every tet against sdf > 0, the sorted unique edges
  * of the active tets and their vertex ids.  Returns the sizes of the outputs: out_vertices = crossing edges,
- * out_faces = triangles.  vertices: float32 [num_vertices,3]; sdf: float32 [num_vertices]; tets: int64 [num_tets,4]. */
+ * out_faces = triangles.  vertices: float32 [num_vertices,3]; sdf: float32 [num_vertices]; tets: int64 [num_tets,4].
+ * A tet index outside [0, num_vertices) is never dereferenced: the call returns P3D_MT_EINDEX (tets may already have
+ * been partly corrected in place). */
 int p3d_mt_prepare(const float* vertices, int64_t num_vertices, int64_t* tets, int64_t num_tets, const float* sdf,
                    void* ws, int64_t* out_vertices, int64_t* out_faces, void* stream);
 

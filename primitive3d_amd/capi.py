@@ -14,7 +14,7 @@ P3D_OK = 0
 SYMBOLS = ("p3d_mc_abi_version", "p3d_last_error", "p3d_mc_workspace_bytes", "p3d_mc_count",
            "p3d_mc_read_counts", "p3d_mc_emit", "p3d_mc_plane_records", "p3d_mc_export_plane_records", "p3d_mc_profile_enable",
            "p3d_mc_profile_read", "p3d_mc_profile_stage_name", "p3d_mc_extract_fused", "p3d_mc_debug_layout",
-           "p3d_mc_workspace_bytes_batched", "p3d_mc_extract_fused_batched")
+           "p3d_mc_workspace_bytes_batched", "p3d_mc_extract_fused_batched", "p3d_mc_reload_tuning")
 
 
 class Slab(ctypes.Structure):
@@ -137,6 +137,11 @@ def emit(grid, thresh, lower, upper, ws, vertices, faces, vertex_keys=None, slab
                                  c_void_p(faces.data_ptr()) if capf else None, capf,
                                  c_void_p(vertex_keys.data_ptr()) if vertex_keys is not None and capv else None,
                                  _stream_ptr(grid)), "p3d_mc_emit")
+
+
+def reload_tuning():
+    """Developer / test hook: the library re-reads its P3D_* launch-shape knobs from the environment."""
+    _check(lib().p3d_mc_reload_tuning(), "p3d_mc_reload_tuning")
 
 
 def profile_enable(mode: int):

@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <memory>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -59,7 +60,7 @@ struct Dims {
 };
 
 struct Ws {  // byte offsets into the workspace
-    size_t hdr, bits, rec, cnt, bsum_v, bbase_v, chunk_sum, wave_off, tile_tris, cur, total;
+    size_t hdr, bits, rec, cnt, bsum_v, bbase_v, chunk_sum, chunk_pre, wave_off, tile_tris, cur, total;
     int64_t nchunks;  // face chunks (tile column x face_chunk_planes planes), all items
     int64_t cpi;      // chunks per item
     int xw;
@@ -97,15 +98,15 @@ __host__ __device__ inline Dims make_dims_stack(int64_t nitems, int64_t rx, int6
     return d;
 }
 
-// face chunk = one tile column over this many planes: 8, doubled until there are at most 4096 chunks (every face tile
-// adds up the chunk totals before its own chunk: a few KiB of coalesced reads)
-// face chunk = one tile column over this many planes: 8, doubled until there are at most 4096 chunks (k_faces adds the
-// chunk totals before a tile's chunk, or reads their prefix); small grids take 4-plane chunks: with 8 planes a 256^3
-// grid has 128 chunk blocks for 256 CUs and each walks 8 planes in sequence (11.4 -> 8.2 us there)
+// face chunk = one tile column over this many planes: 8, doubled while there are more than 4096 chunks and a chunk does
+// not yet span the whole item (k_faces adds the chunk totals before a tile's chunk, or reads their prefix); small grids
+// take 4-plane chunks: with 8 planes a 256^3 grid has 128 chunk blocks for 256 CUs and each walks 8 planes in sequence
+// (11.4 -> 8.2 us there).  A stack of very many small items can still have more than 4096 chunks (one per item and tile
+// column at least): every consumer of the chunk arrays loops over their real number.
 inline int face_chunk_planes(int64_t rx, int64_t tpp, int64_t nitems = 1) {
     int xw = 8;
     if (((rx - 1 + 7) / 8) * tpp * nitems < 512) xw = 4;
-    while (((rx - 1 + xw - 1) / xw) * tpp * nitems > 4096) xw *= 2;
+    while (xw < rx - 1 && ((rx - 1 + xw - 1) / xw) * tpp * nitems > 4096) xw *= 2;
     return xw;
 }
 
@@ -135,6 +136,8 @@ Ws make_ws(const Dims& d) {
     w.cpi = d.xper > 1 ? ((d.xper - 1 + w.xw - 1) / w.xw) * w.tpp : 0;
     w.nchunks = w.cpi * d.nitems;
     w.chunk_sum = o;   // triangles per chunk
+    o = align_up(o + (size_t)(w.nchunks + 1) * 4, 256);
+    w.chunk_pre = o;   // exclusive prefix of chunk_sum (written by the last counting block when there are many chunks)
     o = align_up(o + (size_t)(w.nchunks + 1) * 4, 256);
     w.wave_off = o;    // first face of every (tile, wave), relative to its chunk
     o = align_up(o + (size_t)(w.nb_f + 1) * 4 * 4, 256);
@@ -786,7 +789,7 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
         }
         __syncthreads();
         if (s_last) {
-            const u32 per = (nchunks + kBlock - 1) / kBlock;   // <= 16 (at most 4096 chunks)
+            const u32 per = (nchunks + kBlock - 1) / kBlock;   // <= 16 up to 4096 chunks (more only for stacks of very many items)
             const u32 i0 = (u32)tid * per;
             u32 sum = 0;
             for (u32 k = 0; k < per; ++k)
@@ -1227,6 +1230,25 @@ int env_int(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
+// Launch-shape knobs of the developer sweeps (tools/dev/*.sh) and two test hooks: the environment is read ONCE, at the
+// first call (no getenv in the per-call host path); -1 = "use the built-in rule".
+struct Tuning {
+    int fused_blocks, fused_xt, fused_xt_tail, fused_tail_div, split_rows, small16, compact_blocks, compact_early,
+        test_id_limit, no_chunk_pre;
+};
+Tuning read_tuning() {
+    return Tuning{env_int("P3D_FUSED_BLOCKS", 2048), env_int("P3D_FUSED_XT", -1), env_int("P3D_FUSED_XT_TAIL", -1),
+                  env_int("P3D_FUSED_TAIL_DIV", 4), env_int("P3D_FUSED_SPLIT_ROWS", 1), env_int("P3D_FUSED_SMALL16", 1),
+                  env_int("P3D_COMPACT_BLOCKS", 256), env_int("P3D_COMPACT_EARLY", 3),
+                  env_int("P3D_TEST_ID_LIMIT", 1 << 26), env_int("P3D_NO_CHUNK_PRE", 0)};
+}
+Tuning g_tuning;
+std::once_flag g_tuning_once;
+const Tuning& tuning() {
+    std::call_once(g_tuning_once, [] { g_tuning = read_tuning(); });
+    return g_tuning;
+}
+
 // ---- cursor blocks ---------------------------------------------------------------------------------
 // The streaming kernel's 32 output cursors must be zero when a call starts.
 // Instead of a fill kernel per call the library owns, per (device, stream), a ring of kCursorRing cleared blocks:
@@ -1239,32 +1261,45 @@ struct CursorRing {
     hipStream_t stream = nullptr;
     u64* base = nullptr;
     int cur = 0;
+    std::mutex mu;   // held by a call from the moment it takes its block until its LAST kernel is enqueued
 };
 std::mutex g_ring_mu;
-std::vector<CursorRing> g_rings;
+std::vector<std::unique_ptr<CursorRing>> g_rings;
+
+// A call's hold on its stream's ring.  Two host threads may share one stream (through ctypes the GIL is released): the
+// block a call uses is cleared by the streaming kernel of the call BEFORE it in ring order, and is read by all three of
+// its kernels -- so the calls of one stream must enqueue their launches as whole calls, in ring order.  The lease keeps
+// the ring locked until the caller has enqueued its last kernel (a few tens of microseconds of host time; the GPU
+// serialises the stream anyway).
+struct RingLease {
+    std::unique_lock<std::mutex> lock;
+};
 
 // advance: take the next block (and return the one after it in *zero_next, to be cleared by this call's kernel)
-int cursor_block_for(hipStream_t st, bool advance, u64** block, u64** zero_next) {
+int cursor_block_for(hipStream_t st, RingLease* lease, u64** block, u64** zero_next) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> g(g_ring_mu);
     CursorRing* r = nullptr;
-    for (auto& e : g_rings)
-        if (e.dev == dev && e.stream == st) r = &e;
-    if (!r) {
-        CursorRing n;
-        n.dev = dev;
-        n.stream = st;
-        const size_t bytes = (size_t)kCursorRing * kCursorBlockWords * sizeof(u64);
-        HIP_TRY(hipMalloc((void**)&n.base, bytes));
-        HIP_TRY(hipMemsetAsync(n.base, 0, bytes, st));
-        n.cur = kCursorRing - 1;
-        g_rings.push_back(n);
-        r = &g_rings.back();
+    {
+        std::lock_guard<std::mutex> g(g_ring_mu);
+        for (auto& e : g_rings)
+            if (e->dev == dev && e->stream == st) r = e.get();
+        if (!r) {
+            std::unique_ptr<CursorRing> n(new CursorRing);
+            n->dev = dev;
+            n->stream = st;
+            const size_t bytes = (size_t)kCursorRing * kCursorBlockWords * sizeof(u64);
+            HIP_TRY(hipMalloc((void**)&n->base, bytes));
+            HIP_TRY(hipMemsetAsync(n->base, 0, bytes, st));
+            n->cur = kCursorRing - 1;
+            g_rings.push_back(std::move(n));
+            r = g_rings.back().get();
+        }
     }
-    if (advance) r->cur = (r->cur + 1) % kCursorRing;
+    lease->lock = std::unique_lock<std::mutex>(r->mu);
+    r->cur = (r->cur + 1) % kCursorRing;
     *block = r->base + (size_t)r->cur * kCursorBlockWords;
-    *zero_next = advance ? r->base + (size_t)((r->cur + 1) % kCursorRing) * kCursorBlockWords : nullptr;
+    *zero_next = r->base + (size_t)((r->cur + 1) % kCursorRing) * kCursorBlockWords;
     return P3D_OK;
 }
 
@@ -1487,7 +1522,8 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
     const int64_t per_slab = (int64_t)g.nzt * g.nyt * (stack ? d.nitems : 1);
     // (measured, tools/dev/xt_sweep*.sh / blocks_sweep.sh: about 2000 blocks and at most 16 planes per block -- 12 planes
     //  at 512^3 (120 us vs 124 with 8), 16 at 1024^3 (976 us vs 1140 with the 43 an uncapped rule gave))
-    int64_t want_slabs = (env_int("P3D_FUSED_BLOCKS", 2048) + per_slab - 1) / per_slab;
+    const Tuning& tn = tuning();
+    int64_t want_slabs = (tn.fused_blocks + per_slab - 1) / per_slab;
     int xt = (int)std::min<int64_t>(16, (nplanes + want_slabs - 1) / want_slabs);
     if (xt < 8) {
         const int64_t blocks_at_8 = per_slab * ((nplanes + 7) / 8);
@@ -1497,14 +1533,14 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
             xt = (int)std::max<int64_t>(1, std::min<int64_t>(8, (nplanes + slabs_for_1024 - 1) / slabs_for_1024));
         }
     }
-    xt = env_int("P3D_FUSED_XT", xt);
+    if (tn.fused_xt >= 0) xt = tn.fused_xt;
     if (xt < 1) xt = 1;
     if (xt > nplanes) xt = (int)nplanes;
     g.XT = xt;
     // taper: the last ~1/8 of the planes go in slabs of XT/4 planes
-    const int xt_tail = env_int("P3D_FUSED_XT_TAIL", xt >= 4 ? xt / 4 : xt);
+    const int xt_tail = tn.fused_xt_tail >= 0 ? tn.fused_xt_tail : (xt >= 4 ? xt / 4 : xt);
     const int64_t nslab_all = (nplanes + xt - 1) / xt;
-    int64_t n_big = nslab_all - std::max<int64_t>(1, nslab_all / env_int("P3D_FUSED_TAIL_DIV", 4));
+    int64_t n_big = nslab_all - std::max<int64_t>(1, nslab_all / std::max(1, tn.fused_tail_div));
     if (xt_tail >= xt || nslab_all < 8) n_big = nslab_all;
     g.n_big = (int)n_big;
     g.XT_tail = xt_tail > 0 ? xt_tail : 1;
@@ -1535,7 +1571,7 @@ void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const 
     // chunks (rz <= 256: 4 chunks x 7 rows -- the 8-chunk tile would be half empty -- or, for a single small grid,
     // 16-unit tiles of 4 chunks x 3 rows), short rows (2 chunks x 15 rows)
     const int rem = (int)(d.ncz % 8);
-    if (d.ncz >= 9 && rem >= 1 && rem <= 2 && env_int("P3D_FUSED_SPLIT_ROWS", 1)) {
+    if (d.ncz >= 9 && rem >= 1 && rem <= 2 && tuning().split_rows) {
         // rows of 8k + 1..2 chunks (rz = 513, 517, 600, 1025: grids of 2^n + 1 samples are common): the 8-chunk tiles take
         // the first 8k chunks, a second launch with the 2-chunk tile the rest -- a last 8-chunk tile would be 1/8 or 1/4
         // full (513 x 511 x 517: 169 -> 155 us; with 3..4 chunks left over the split measured no gain)
@@ -1555,7 +1591,7 @@ void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const 
              ((d.ry + 27) / 28) * (d.stack ? d.nitems : 1) * ((x_hi - x_lo + 7) / 8) >= 1024)
         launch_fused<T, 4, 7>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
                               store_rows, x_lo, x_hi, ev0, ev1, st);
-    else if (d.ncz >= 3 && env_int("P3D_FUSED_SMALL16", 1))
+    else if (d.ncz >= 3 && tuning().small16)
         // a single small grid: 16-unit tiles (4 chunks x 3 rows + halo row) -- twice the waves of the 8-chunk tile, none
         // of them half empty
         launch_fused<T, 4, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
@@ -1590,15 +1626,15 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     u64* bits = (u64*)(ws + w.bits);
     uint2* rec = (uint2*)(ws + w.rec);
     u32 *csum = (u32*)(ws + w.chunk_sum), *woff = (u32*)(ws + w.wave_off);
-    // exclusive prefix of the chunk totals, written by the last counting block when there are many chunks (the counting
-    // call's scan array is free here)
-    u32* cpre = w.nchunks > kPreMinChunks ? (u32*)(ws + w.bbase_v) : nullptr;
+    // exclusive prefix of the chunk totals, written by the last counting block when there are many chunks
+    // (P3D_NO_CHUNK_PRE=1: escape hatch and test reference -- every face tile adds the chunk totals up itself)
+    u32* cpre = (w.nchunks > kPreMinChunks && !tuning().no_chunk_pre) ? (u32*)(ws + w.chunk_pre) : nullptr;
     // Vertex ids handed out by the streaming kernel are region * 2^26 + slot (a fixed stride, so they stay
     // unambiguous even when a region outgrows its share of the scratch buffer); readers make them dense on the fly.
     // Storage is store_rows rows per region; without a scratch buffer nothing is stored (pure count + ids).
     const u32 region_rows = 1u << 26;
     // (test hook: P3D_TEST_ID_LIMIT pretends the id space of a region is smaller, to reach the callers' fallback)
-    const u32 id_limit = (u32)std::min<int64_t>(region_rows, std::max(1, env_int("P3D_TEST_ID_LIMIT", 1 << 26)));
+    const u32 id_limit = (u32)std::min<int64_t>(region_rows, std::max(1, tuning().test_id_limit));
     const u32 store_rows = scratch ? (u32)std::min<int64_t>(scratch_rows / kRegions, (int64_t)region_rows) : 0u;
     const int part = slab ? slab->part : 0;
     // parts (p3d_mc_slab.part): 0 everything; 1 planes [0, split) only; 2 planes [split, rx) + finalize;
@@ -1611,9 +1647,10 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     // extraction made of several calls keeps them inside its own workspace header instead, cleared by its first part:
     // other extractions may run on the same stream in between (the in-process multi-rank harness does exactly that).
     u64 *cursors = nullptr, *zero_next = nullptr;
+    RingLease lease;   // (released when this function returns: every launch of the call is enqueued by then)
     const bool new_block = part == 0 || part == 1 || (part == 3 && slab->split_plane == 0);
     if (part == 0) {
-        if (int rc = cursor_block_for(st, true, &cursors, &zero_next)) return rc;
+        if (int rc = cursor_block_for(st, &lease, &cursors, &zero_next)) return rc;
     } else {
         cursors = hdr + H_CURSORS;
         if (new_block)   // (an ordinary kernel: the runtime's fill path starts late, see fused_stack_impl)
@@ -1647,8 +1684,8 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     // the copy of the vertex regions is split over the two launches: `early` of `nparts` slices of every region ride
     // with the counting kernel (VALU-bound, HBM idle), the rest with k_faces
     const bool copy = scratch && capv > 0;
-    const int nparts = copy ? std::max(1, env_int("P3D_COMPACT_BLOCKS", 256) / kRegions) : 1;
-    const int early = (copy && w.nchunks > 0) ? std::min(nparts - 1, env_int("P3D_COMPACT_EARLY", 3)) : 0;
+    const int nparts = copy ? std::max(1, tuning().compact_blocks / kRegions) : 1;
+    const int early = (copy && w.nchunks > 0) ? std::min(nparts - 1, tuning().compact_early) : 0;
     if (w.nchunks > 0 && part != 5) {
         StageTimer tm(ST_FACES_COUNT, st);
         const CompactArgs cpe{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, early * kRegions, 0, nparts, 0,
@@ -1685,14 +1722,15 @@ int fused_stack_impl(const T* grids, const Dims& d, const Ws& w, float thresh, c
     uint2* rec = (uint2*)(ws + w.rec);
     u32 *csum = (u32*)(ws + w.chunk_sum), *woff = (u32*)(ws + w.wave_off);
     u64* cursors = (u64*)(ws + w.cur);
-    u32* cpre = w.nchunks > kPreMinChunks ? (u32*)(ws + w.bbase_v) : nullptr;   // (see fused_impl)
+    // (P3D_NO_CHUNK_PRE=1: escape hatch and test reference -- every face tile adds the chunk totals up itself)
+    u32* cpre = (w.nchunks > kPreMinChunks && !tuning().no_chunk_pre) ? (u32*)(ws + w.chunk_pre) : nullptr;   // (see fused_impl)
     // (an ordinary kernel, not hipMemsetAsync: the runtime's fill path left the GPU idle for 11 us before it ran)
     {
         const int64_t nwords = (int64_t)d.nitems * kCursorBlockWords;
         hipLaunchKernelGGL(k_zero_words, dim3((u32)((nwords + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, cursors, nwords);
     }
     const u32 region_rows = 1u << 26;
-    const u32 id_limit = (u32)std::min<int64_t>(region_rows, std::max(1, env_int("P3D_TEST_ID_LIMIT", 1 << 26)));
+    const u32 id_limit = (u32)std::min<int64_t>(region_rows, std::max(1, tuning().test_id_limit));
     const u32 store_rows =
         scratch ? (u32)std::min<int64_t>(scratch_rows / ((int64_t)kRegions * d.nitems), (int64_t)region_rows) : 0u;
     const bool timed = g_prof_mode != 0;
@@ -1869,6 +1907,12 @@ int p3d_mc_debug_layout(int64_t rx, int64_t ry, int64_t rz, size_t* off_bits, si
     *off_records = w.rec;
     *num_units = d.U;
     *chunks_per_row = d.ncz;
+    return P3D_OK;
+}
+
+int p3d_mc_reload_tuning(void) {   // dev / test hook: re-read the P3D_* knobs (not for use beside running calls)
+    (void)tuning();
+    g_tuning = read_tuning();
     return P3D_OK;
 }
 

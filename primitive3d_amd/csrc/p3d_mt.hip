@@ -55,7 +55,7 @@ __device__ const unsigned char k_edge_b[6] = {1, 2, 3, 2, 3, 3};
 struct MtWs {  // byte offsets into the workspace
     size_t hdr, occ, cas, wmask, wcnt, wbase, vlist, tcount, tscan, table, rank, uniq, sorted, temp, temp_bytes, total;
 };
-enum { M_NVALID = 0, M_V = 1, M_N1 = 2, M_N2 = 3 };
+enum { M_NVALID = 0, M_V = 1, M_N1 = 2, M_N2 = 3, M_BADIDX = 4 /* some tet index is out of range */ };
 constexpr u64 kEmpty = ~0ull;   // (no key: lo < hi < 2^32 and hb <= 32)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -141,11 +141,11 @@ __global__ void __launch_bounds__(kBlock) k_mt_occ(const float* __restrict__ sdf
 // ALIGNED: the tet array starts on a 16-byte boundary (two 16-byte loads per tet instead of four 8-byte ones)
 template <bool ALIGNED>
 __global__ void __launch_bounds__(kBlock) k_mt_classify(const float* __restrict__ vertices, int64_t* __restrict__ tets,
-                                                        int64_t nt, const u32* __restrict__ occ,
+                                                        int64_t nt, int64_t nv, const u32* __restrict__ occ,
                                                         unsigned char* __restrict__ cas, u64* __restrict__ wmask,
-                                                        u32* __restrict__ wcnt) {
+                                                        u32* __restrict__ wcnt, u64* __restrict__ hdr) {
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    bool active = false;
+    bool active = false, bad = false;
     if (t < nt) {
         int64_t i0, i1, i2, i3;
         if (ALIGNED) {
@@ -154,6 +154,10 @@ __global__ void __launch_bounds__(kBlock) k_mt_classify(const float* __restrict_
         } else {
             i0 = tets[4 * t], i1 = tets[4 * t + 1], i2 = tets[4 * t + 2], i3 = tets[4 * t + 3];
         }
+        // an index outside [0, nv) is never dereferenced (the reference's indexing raises): the tet is skipped and the
+        // call fails with P3D_MT_EINDEX
+        bad = (u64)i0 >= (u64)nv || (u64)i1 >= (u64)nv || (u64)i2 >= (u64)nv || (u64)i3 >= (u64)nv;
+        if (bad) i0 = i1 = i2 = i3 = 0;   // (nv >= 1 whenever a tet exists and is valid; see the host check)
         // orientation: sign of det [1 p0; 1 p1; 1 p2; 1 p3] = det [p1-p0; p2-p0; p3-p0]  (:50-65; float64 from the
         // float32 coordinates -- the reference's float32 LU gives the same sign on non-degenerate cells)
         const P3* __restrict__ pts = (const P3*)vertices;
@@ -178,10 +182,16 @@ __global__ void __launch_bounds__(kBlock) k_mt_classify(const float* __restrict_
         cas[t] = (unsigned char)c;
         active = c != 0u && c != 15u;                                                       // :153-154
     }
+    if (t < nt && bad) {   // inactive
+        cas[t] = 0;
+        active = false;
+    }
     const u64 m = __ballot(active);
+    const u64 anybad = __ballot(bad);
     if ((threadIdx.x & 63) == 0 && t < nt) {
         wmask[t >> 6] = m;
         wcnt[t >> 6] = (u32)__popcll(m);
+        if (anybad) hdr[M_BADIDX] = 1ull;   // (every writer stores the same value)
     }
 }
 
@@ -250,8 +260,8 @@ __device__ inline void mt_report(u64* mb, u64 seq, u64 a, u64 b, u64 c) {
     __hip_atomic_store(&mb[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ void k_mt_report_nvalid(const u32* __restrict__ last_inclusive, u64* mb, u64 seq) {
-    mt_report(mb, seq, (u64)*last_inclusive, 0ull, 0ull);
+__global__ void k_mt_report_nvalid(const u32* __restrict__ last_inclusive, const u64* __restrict__ hdr, u64* mb, u64 seq) {
+    mt_report(mb, seq, (u64)*last_inclusive, hdr[M_BADIDX], 0ull);
 }
 
 __global__ void k_mt_totals(const u64* __restrict__ nuniq, const u64* __restrict__ tcount, const u64* __restrict__ tscan,
@@ -268,8 +278,9 @@ __global__ void k_mt_totals(const u64* __restrict__ nuniq, const u64* __restrict
 
 // slot of a key that IS in the hash set
 __device__ inline u64 find_slot(const u64* __restrict__ table, u64 table_mask, u64 key) {
+    // (bounded: a caller that hands p3d_mt_emit other tets than p3d_mt_prepare corrected gets a wrong id, not a hang)
     u64 h = mix64(key) & table_mask;
-    while (table[h] != key) h = (h + 1) & table_mask;
+    for (u64 probes = 0; table[h] != key && probes <= table_mask; ++probes) h = (h + 1) & table_mask;
     return h;
 }
 
@@ -448,6 +459,7 @@ int p3d_mt_prepare(const float* vertices, int64_t num_vertices, int64_t* tets, i
     if (!ws_ || !out_vertices || !out_faces) return fail(P3D_MT_EINVAL, "null pointer%s");
     if (num_tets > 0 && (!vertices || !tets || !sdf)) return fail(P3D_MT_EINVAL, "null input%s");
     if (int rc = check_sizes(num_vertices, num_tets)) return rc;
+    if (num_tets > 0 && num_vertices < 1) return fail(P3D_MT_EINDEX, "tets without vertices%s");
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)ws_;
     const MtWs w = make_ws(num_vertices, num_tets);
@@ -468,25 +480,29 @@ int p3d_mt_prepare(const float* vertices, int64_t num_vertices, int64_t* tets, i
         hipLaunchKernelGGL(k_mt_occ, dim3(blocks_for(num_vertices)), dim3(kBlock), 0, st, sdf, num_vertices, occ, hdr);
         if (((uintptr_t)tets & 15u) == 0)
             hipLaunchKernelGGL((k_mt_classify<true>), dim3(blocks_for(num_tets)), dim3(kBlock), 0, st, vertices, tets, num_tets,
-                               (const u32*)occ, cas, wmask, wcnt);
+                               num_vertices, (const u32*)occ, cas, wmask, wcnt, hdr);
         else
             hipLaunchKernelGGL((k_mt_classify<false>), dim3(blocks_for(num_tets)), dim3(kBlock), 0, st, vertices, tets,
-                               num_tets, (const u32*)occ, cas, wmask, wcnt);
+                               num_tets, num_vertices, (const u32*)occ, cas, wmask, wcnt, hdr);
         // inclusive: its last element is the number of active tets (a wave's first slot = its element - its count)
         HIP_TRY(rocprim::inclusive_scan(temp, tb, wcnt, wbase, (size_t)nw, rocprim::plus<u32>(), st));
         // (the reference synchronises here too: tets[valid_tets], :157)
         volatile u64* slot = nullptr;
         u64 seq = 0, got[3];
         u64* mb = mt_mailbox_take(&slot, &seq);
-        if (mb) hipLaunchKernelGGL(k_mt_report_nvalid, dim3(1), dim3(1), 0, st, wbase + (nw - 1), mb, seq);
+        if (mb) hipLaunchKernelGGL(k_mt_report_nvalid, dim3(1), dim3(1), 0, st, wbase + (nw - 1), (const u64*)hdr, mb, seq);
+        u64 bad_index = 0;
         if (mb && mt_mailbox_wait(slot, seq, got)) {
             sz.nvalid = (int64_t)got[0];
+            bad_index = got[1];
         } else {
             u32 nvalid = 0;
             HIP_TRY(hipMemcpyAsync(&nvalid, wbase + (nw - 1), sizeof(u32), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(&bad_index, hdr + M_BADIDX, sizeof(u64), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             sz.nvalid = (int64_t)nvalid;
         }
+        if (bad_index) return fail(P3D_MT_EINDEX, "a tet index is outside [0, num_vertices)%s");
     }
     if (sz.nvalid > 0) {
         const size_t slots = table_slots(sz.nvalid);

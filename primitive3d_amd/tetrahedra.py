@@ -43,6 +43,8 @@ def lib():
 
 
 def _check(rc, what):
+    if rc == -4:   # P3D_MT_EINDEX: the reference's `vertices[tets]` raises IndexError (marching_tetrahedras.py:60)
+        raise IndexError(f"{what}: {lib().p3d_mt_last_error().decode()}")
     if rc != 0:
         raise RuntimeError(f"{what} failed ({rc}): {lib().p3d_mt_last_error().decode()}")
 

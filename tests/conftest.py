@@ -38,3 +38,28 @@ def gpu(built):
     if not torch.cuda.is_available():
         pytest.fail("test marked gpu but no GPU is visible (torch.cuda.is_available() is False)")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def tuning_env(built):
+    """Set P3D_* knobs of the native library for one test.  The library reads them once per process
+    (include/p3d_mc.h, p3d_mc_reload_tuning): set(name, value) changes the environment and makes the library re-read
+    it; the old environment is restored, and re-read, when the test ends."""
+    from primitive3d_amd import capi
+    saved = {}
+
+    def set_(name, value):
+        saved.setdefault(name, os.environ.get(name))
+        if value is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = str(value)
+        capi.reload_tuning()
+
+    yield set_
+    for name, old in saved.items():
+        if old is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = old
+    capi.reload_tuning()

@@ -18,7 +18,7 @@ def test_header_functions_are_exported(built):
     from primitive3d_amd._build import capi_path
     lib = ctypes.CDLL(str(capi_path()))
     names = declared_functions()
-    assert "p3d_mc_extract_fused" in names and "p3d_mc_count" in names and len(names) >= 11
+    assert "p3d_mc_extract_fused" in names and "p3d_mc_count" in names and len(names) >= 12
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/p3d_mc.h but not exported"
     assert sorted(capi.SYMBOLS) == names, "capi.py binds exactly the declared entry points"
@@ -34,7 +34,7 @@ def test_tetrahedra_header_functions_are_exported(built):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/p3d_mt.h but not exported"
     assert sorted(tetrahedra.SYMBOLS) == names
-    assert tetrahedra.lib().p3d_mt_abi_version() == 1
+    assert tetrahedra.lib().p3d_mt_abi_version() == 2
     nbytes = ctypes.c_size_t(0)
     assert tetrahedra.lib().p3d_mt_workspace_bytes(2056, 12045, ctypes.byref(nbytes)) == 0 and nbytes.value > 12045 * 200
     assert tetrahedra.lib().p3d_mt_workspace_bytes(1 << 33, 4, ctypes.byref(nbytes)) < 0
@@ -56,7 +56,7 @@ def test_raycaster_header_functions_are_exported(built):
 
 def test_host_only_entry_points(built):
     from primitive3d_amd import capi
-    assert capi.lib().p3d_mc_abi_version() == 5
+    assert capi.lib().p3d_mc_abi_version() == 6
     n512 = capi.workspace_bytes(512, 512, 512)
     assert 0.25 * 512 ** 3 < n512 < 0.40 * 512 ** 3  # bits + records + counts: ~0.3 B/voxel (reference: 12 B/voxel)
     lay = capi.debug_layout(10, 9, 66)
@@ -64,6 +64,22 @@ def test_host_only_entry_points(built):
     import pytest
     with pytest.raises(capi.P3DError):
         capi.workspace_bytes(0, 4, 4)
+
+
+def test_workspace_of_a_stack_of_many_small_items(built):
+    """A stack of more than 4096 small grids has more face chunks than the 4096 the chunk size is doubled for (one per
+    item and tile column at least): the sizing loop must end (it once overflowed an int and divided by zero) and the
+    workspace must grow with the item count (host-only: no compute call)."""
+    from primitive3d_amd import capi
+    w4096 = capi.workspace_bytes_batched(4096, 32, 32, 32)
+    w4097 = capi.workspace_bytes_batched(4097, 32, 32, 32)
+    wmax = capi.workspace_bytes_batched(65535, 32, 32, 32)
+    assert w4096 < w4097 < wmax
+    assert wmax > 65535 * (32 * 32 * 16 + 32 * 16 * 8)   # bits + records + per-item cursors, at least
+    assert capi.workspace_bytes_batched(2048, 256, 256, 256) > 2048 * 256 ** 3 // 8 * 2   # tpp = 4: 8192 tile columns
+    import pytest
+    with pytest.raises(capi.P3DError):
+        capi.workspace_bytes_batched(65536, 32, 32, 32)
 
 
 def test_product_path_has_no_cpu_fallback():

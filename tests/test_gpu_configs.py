@@ -150,15 +150,46 @@ def test_batched_call_equals_per_item_oracle(gpu, built, shape, B, dtype):
     assert torch.equal(vo2, vo) and torch.equal(fo2, fo)
 
 
-def test_batched_call_falls_back_item_by_item(gpu, built, monkeypatch):
+def test_batched_call_falls_back_item_by_item(gpu, built, tuning_env):
     """P3D_TEST_ID_LIMIT makes every region report an id-space overflow: the wrapper must return the same meshes
     through its per-item path."""
     from oracle import oracle_count
     grids = torch.from_numpy(np.random.default_rng(3).standard_normal((3, 10, 11, 70)).astype(np.float32))
-    monkeypatch.setenv("P3D_TEST_ID_LIMIT", "4")
+    tuning_env("P3D_TEST_ID_LIMIT", "4")
     v, f, vo, fo = built.marching_cubes_batched(grids.to(gpu), 0.0)
     for b in range(3):
         assert (int(vo[b + 1] - vo[b]), int(fo[b + 1] - fo[b])) == oracle_count(grids[b].numpy(), 0.0)
+
+
+@pytest.mark.parametrize("kind", ["stack", "single"])
+def test_chunk_prefix_handoff_under_load(gpu, built, tuning_env, kind):
+    """With more than 1024 face chunks the LAST counting block to finish turns the chunk totals into their exclusive
+    prefix for k_faces (sc1 stores / loads and a drained store before the completion counter, no agent-scope fence:
+    p3d_mc.hip, k_face_count_walk).  A stale total would silently shift every face offset behind it.  Reference =
+    the same call with P3D_NO_CHUNK_PRE=1 (every face tile adds the totals up itself): the triangle soup must be
+    the same bit for bit (vertex ids are arrival order, so the soups are compared), counts equal to the independent torch count -- repeated,
+    back to back, so that the hand-off runs on a loaded chip with warm caches."""
+    from primitive3d_amd.fields import perlin_grid
+    if kind == "stack":   # 20 items x 68 chunks = 1360 chunks
+        grids = torch.stack([perlin_grid((130, 256, 256), period=32, seed=s, device=gpu).half() for s in range(20)])
+        run = lambda: built.marching_cubes_batched(grids, 0.0)[:2]
+        expect = [sum(x) for x in zip(*[torch_counts(grids[b], 0.0) for b in range(20)])]
+    else:                 # 65 x 16 = 1040 chunks
+        g = perlin_grid((520, 512, 512), period=48, seed=5, device=gpu).half()
+        from primitive3d_amd import capi
+        run = lambda: capi.extract_fused(g, 0.0, cap_vertices=1 << 24, cap_faces=1 << 25)
+        expect = list(torch_counts(g, 0.0))
+    tuning_env("P3D_NO_CHUNK_PRE", "1")
+    v0, f0 = run()
+    torch.cuda.synchronize()
+    assert [v0.shape[0], f0.shape[0]] == expect
+    key = lambda v, f: soup_hashes(v, f)
+    h0 = key(v0, f0)
+    tuning_env("P3D_NO_CHUNK_PRE", None)
+    for _ in range(12):
+        v, f = run()
+        assert (v.shape[0], f.shape[0]) == (v0.shape[0], f0.shape[0])
+        assert torch.equal(key(v, f), h0)
 
 
 def test_c5_32x256_fp16_full_batch(gpu, built):

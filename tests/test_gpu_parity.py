@@ -190,10 +190,10 @@ def test_counts_without_the_mailbox(gpu):
 
 
 @pytest.mark.parametrize("early", ["0", "1", "7"])
-def test_vertex_copy_split_between_the_two_face_launches(gpu, monkeypatch, early):
+def test_vertex_copy_split_between_the_two_face_launches(gpu, tuning_env, early):
     """P3D_COMPACT_EARLY slices of every vertex region are copied by blocks riding with the counting kernel, the
     rest by blocks riding with k_faces: any split gives the same mesh."""
-    monkeypatch.setenv("P3D_COMPACT_EARLY", early)
+    tuning_env("P3D_COMPACT_EARLY", early)
     g, thresh, lower, upper = small_cases()["perlin_40x24x96_thr"]
     _assert_same_mesh(_hip_extract_fused(gpu, g, thresh, lower, upper), oracle_extract(g, thresh, lower, upper))
 
@@ -213,12 +213,12 @@ def test_adapter_on_a_row_with_a_nearly_empty_last_z_tile(gpu, built):
     assert np.array_equal(soup(v.cpu().numpy(), f.cpu().numpy()), soup(rv, rf))
 
 
-def test_region_id_space_overflow_falls_back_to_the_counting_call(gpu, built, monkeypatch):
+def test_region_id_space_overflow_falls_back_to_the_counting_call(gpu, built, tuning_env):
     """A region that numbers more than 2^26 vertices makes the one-pass ids ambiguous (include/p3d_mc.h,
     p3d_mc_read_counts bit 1).  P3D_TEST_ID_LIMIT pretends the id space is tiny: the flag must come back, and both the
     ctypes flow and the pybind adapter must renumber with p3d_mc_count + p3d_mc_emit and still return the exact mesh."""
     from primitive3d_amd import capi
-    monkeypatch.setenv("P3D_TEST_ID_LIMIT", "16")
+    tuning_env("P3D_TEST_ID_LIMIT", "16")
     g, thresh, lower, upper = small_cases()["noise_33x17x200"]
     t = torch.from_numpy(g).to(gpu)
     ws = torch.empty(capi.workspace_bytes(*t.shape), dtype=torch.uint8, device=gpu)
@@ -231,7 +231,7 @@ def test_region_id_space_overflow_falls_back_to_the_counting_call(gpu, built, mo
     assert np.array_equal(soup(v.cpu().numpy(), f.cpu().numpy()), soup(ref[0], ref[1]))
     v, f = built.libPrim3D.marching_cubes(t, thresh, lower, upper)
     assert np.array_equal(soup(v.cpu().numpy(), f.cpu().numpy()), soup(ref[0], ref[1]))
-    monkeypatch.delenv("P3D_TEST_ID_LIMIT")
+    tuning_env("P3D_TEST_ID_LIMIT", None)
     capi.extract_fused_raw(t, thresh, lower, upper, ws, None, None)
     assert capi.read_counts(ws, with_flags=True)[2] == 0
 
@@ -281,6 +281,52 @@ def test_adapter_modes_in_a_fresh_process(gpu, env):
         assert got[2:] == [nv, nf], got
     else:     # default: rows [0, V) of a buffer that may be up to 1/8 + 4096 rows longer
         assert nv <= got[2] <= nv + nv // 8 + 4096 and nf <= got[3] <= nf + nf // 8 + 4096, got
+
+
+def test_threads_sharing_one_stream_through_the_c_abi(gpu, built):
+    """Four host threads enqueue whole extractions on ONE stream through ctypes (which releases the GIL, so the calls
+    really interleave on the host): the library hands every call a block of the stream's cursor ring and the streaming
+    kernel of the call before it clears that block, so the launches of a call must be enqueued as a whole, in ring
+    order (per-stream lock, include/p3d_mc.h "Threads").  Every result must equal the single-threaded one."""
+    import threading
+    from bench import soup_hashes
+    from primitive3d_amd import capi
+    from primitive3d_amd.fields import perlin_grid
+    shapes = [(96, 80, 130), (64, 64, 64), (128, 128, 200), (40, 200, 520)]
+    grids = [perlin_grid(s, period=24, seed=10 + i, device=gpu) for i, s in enumerate(shapes)]
+    ref = []
+    for g in grids:
+        v, f = capi.extract_fused(g, 0.0)
+        torch.cuda.synchronize()
+        ref.append((v.shape[0], f.shape[0], soup_hashes(v, f)[0]))
+    st = torch.cuda.Stream(device=gpu)
+    errors, results = [], []
+    lock = threading.Lock()
+
+    def worker(tid):
+        try:
+            with torch.cuda.stream(st):   # (the current stream is per thread: every thread selects the shared one)
+                for it in range(30):
+                    k = (it * 3 + tid) % len(grids)
+                    v, f = capi.extract_fused(grids[k], 0.0)
+                    if (v.shape[0], f.shape[0]) != ref[k][:2]:
+                        errors.append((tid, it, k, tuple(v.shape), tuple(f.shape)))
+                    elif it % 5 == 0:
+                        with lock:
+                            results.append((k, v, f))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    st.synchronize()
+    torch.cuda.synchronize()
+    assert not errors, errors[:5]
+    for k, v, f in results:
+        assert torch.equal(soup_hashes(v, f)[0], ref[k][2]), f"grid {k}: triangle soup differs"
 
 
 def test_threads_on_their_own_streams(gpu, built):

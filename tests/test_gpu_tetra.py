@@ -37,6 +37,26 @@ def test_reference_vectors(gpu, built, path, where):
     assert torch.equal(v2, v) and torch.equal(f2, f)   # (tets are already oriented now: idempotent)
 
 
+SLIVERS = sorted((Path(__file__).parent / "golden").glob("tetraslivers_*.npz"))
+
+
+@pytest.mark.parametrize("path", SLIVERS, ids=[p.stem for p in SLIVERS])
+def test_reference_vectors_with_slivers(gpu, built, path):
+    """The reference's outputs on meshes that keep their slivers: the library (float64 determinant) may orient only
+    tets whose determinant is rounding noise differently from the reference's float32 LU (tests/tetra_compare.py); the
+    same bar against the oracle."""
+    from tests.tetra_compare import assert_equal_modulo_flat_tets
+    g = np.load(path)
+    tets = torch.from_numpy(g["tets"].copy()).to(gpu)
+    v, f, ti = built.marching_tetrahedras(torch.from_numpy(g["points"]).to(gpu), tets, torch.from_numpy(g["sdf"]).to(gpu), True)
+    out = (v.cpu().numpy(), f.cpu().numpy(), ti.cpu().numpy(), tets.cpu().numpy())
+    assert_equal_modulo_flat_tets(g["points"], g["tets"], out, (g["verts"], g["faces"], g["tet_idx"], g["tets_after"]),
+                                  max_differing=8)
+    # (library and oracle both take float64 determinants, but by different formulas -- cofactor expansion vs LAPACK's
+    #  LU: on rounding-noise determinants they too may differ, and only there)
+    assert_equal_modulo_flat_tets(g["points"], g["tets"], out, mt_oracle(g["points"], g["tets"], g["sdf"]), max_differing=16)
+
+
 def _grid_tets(n, seed):
     """n^3 cubes of 5 tetrahedra each on a jittered lattice (an SDF-friendly mesh with hundreds of thousands of tets)."""
     rng = np.random.default_rng(seed)
@@ -96,6 +116,13 @@ def test_argument_errors(gpu, built):
         built.marching_tetrahedras(P, T[:, :3], S)
     v, f = built.marching_tetrahedras(P, T, S)
     assert v.shape == (0, 3) and f.shape == (0, 3)
+    # a tet index outside [0, N): the reference's `vertices[tets]` raises IndexError; here it is never dereferenced
+    S2 = torch.tensor([-1.0, 1.0, 1.0, 1.0], device=gpu)
+    for bad in ([[0, 1, 2, 4]], [[0, -1, 2, 3]], [[0, 1, 2, 3], [1 << 40, 1, 2, 3]]):
+        with pytest.raises(IndexError):
+            built.marching_tetrahedras(P, torch.tensor(bad, device=gpu), S2)
+    v, f = built.marching_tetrahedras(torch.rand(4, 3, device=gpu), T.clone(), S2)   # (the library still works afterwards)
+    assert v.shape == (3, 3) and f.shape == (1, 3)
 
 
 @pytest.mark.parametrize("script,args", [("sphere.py", ["--out", ""]), ("bunny_sdf.py", ["--out", ""]),

@@ -36,3 +36,23 @@ def test_tensor_op_baseline_reproduces_reference_outputs(path):
     assert np.array_equal(tets.numpy(), g["tets_after"])
     assert np.array_equal(f.numpy(), g["faces"]) and np.array_equal(ti.numpy(), g["tet_idx"])
     assert np.array_equal(v.numpy(), g["verts"])
+
+
+SLIVERS = sorted((Path(__file__).parent / "golden").glob("tetraslivers_*.npz"))
+
+
+@pytest.mark.parametrize("path", SLIVERS, ids=[p.stem for p in SLIVERS])
+def test_orientation_on_slivers_against_the_reference(path):
+    """Meshes that KEEP their slivers (about 1600 of 14.9 k tets have |det| < 1e-7), outputs of the reference itself.
+    The oracle's float64 determinant may orient a tet differently from the reference's float32 `torch.det`
+    (marching_tetrahedras.py:50-65) only where the determinant is rounding noise (|det| < 1e-12); measured on these
+    vectors: 0 tets at a jitter of 1e-6, 6 of 14 847 at 3e-8 (all with |det| < 1e-25), and then only the winding of
+    those tets' triangles differs (tests/tetra_compare.py; documented in include/p3d_mt.h)."""
+    from tests.tetra_compare import assert_equal_modulo_flat_tets
+    g = np.load(path)
+    assert len(SLIVERS) == 2 and g["tets"].shape[0] > 14000
+    p = g["points"][g["tets"]].astype(np.float64)
+    assert int((np.abs(np.linalg.det(p[:, 1:] - p[:, :1])) < 1e-7).sum()) > 1500, "the golden keeps its slivers"
+    n = assert_equal_modulo_flat_tets(g["points"], g["tets"], mt_oracle(g["points"], g["tets"], g["sdf"]),
+                                      (g["verts"], g["faces"], g["tet_idx"], g["tets_after"]), max_differing=8)
+    assert n == (0 if "1e-6" in path.stem else 6)

@@ -47,6 +47,23 @@ def random_mesh(seed, npts, noisy):
     return pts, tets, sdf
 
 
+def sliver_mesh(seed, jitter):
+    """A mesh that KEEPS its slivers: Delaunay (qhull QJ) of a regular 12^3 lattice whose points are jittered by
+    `jitter` (cells of the lattice are cospherical: thousands of nearly flat tetrahedra whose determinant is a few ulps
+    of rounding noise) plus 500 random points.  Written as tests/golden/tetraslivers_*.npz: on these the reference's
+    float32 `torch.det` (:50-65) and a float64 determinant may orient a nearly flat tet differently."""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed)
+    lat = np.stack(np.meshgrid(*[np.linspace(-0.5, 0.5, 12)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    pts = (lat + rng.uniform(-jitter, jitter, size=lat.shape)).astype(np.float32)
+    pts = np.concatenate([pts, rng.uniform(-1.0, 1.0, size=(500, 3)).astype(np.float32)])
+    tets = Delaunay(pts.astype(np.float64), qhull_options="QJ").simplices.astype(np.int64)
+    swap = rng.random(len(tets)) < 0.5
+    tets[swap] = tets[swap][:, [1, 0, 2, 3]]
+    sdf = (np.linalg.norm(pts, axis=1) - 0.45 + 0.05 * np.sin(7.0 * pts[:, 0])).astype(np.float32)
+    return pts, tets, sdf
+
+
 def run(ref, pts, tets, sdf):
     t = torch.from_numpy(tets.copy())
     v, f, ti = ref.marching_tetrahedras(torch.from_numpy(pts), t, torch.from_numpy(sdf), True)
@@ -69,6 +86,14 @@ def main():
     for name, c in cases.items():
         np.savez_compressed(OUT / f"tetra_{name}.npz", **c)
         print(name, "V", c["verts"].shape, "F", c["faces"].shape, "flipped", int((c["tets_after"] != c["tets"]).any(1).sum()))
+    # meshes with their slivers kept (separate file prefix: compared modulo the nearly flat tets, tests/test_tetra_cpu.py)
+    for name, (seed, jitter) in {"jitter_1e-6": (5, 1e-6), "jitter_3e-8": (5, 3e-8)}.items():
+        c = run(ref, *sliver_mesh(seed, jitter))
+        np.savez_compressed(OUT / f"tetraslivers_{name}.npz", **c)
+        p = c["points"][c["tets"]].astype(np.float64)
+        det = np.linalg.det(p[:, 1:] - p[:, :1])
+        print("slivers", name, "T", len(c["tets"]), "|det| < 1e-7:", int((np.abs(det) < 1e-7).sum()), "V", c["verts"].shape,
+              "F", c["faces"].shape)
     return 0
 
 
