@@ -82,6 +82,9 @@ typedef struct p3d_mc_slab {
                                     rank's count) and ignores the two fields above: the host never waits for the
                                     other ranks' counts, the all-gather result stays on the device. */
     int32_t rank;                /* index of this rank in rank_counts */
+    int32_t rank_counts_stride;  /* int64 elements between two ranks' counts (0 = 1): the multi-GPU wrapper all-gathers
+                                    the first three header words of every rank's workspace (V, -, flags), so that every
+                                    rank also learns every rank's overflow flags; the counts are then 3 apart */
 } p3d_mc_slab;
 
 /* Bytes of device scratch p3d_mc_count / p3d_mc_emit need for an [rx,ry,rz] grid.
@@ -192,7 +195,7 @@ const char* p3d_mc_profile_stage_name(int stage);
 
 /* Developer / test hook (no reference counterpart).  The launch-shape knobs of the developer sweeps and the two test
  * hooks (P3D_FUSED_BLOCKS, P3D_FUSED_XT, P3D_FUSED_XT_TAIL, P3D_FUSED_TAIL_DIV, P3D_FUSED_SPLIT_ROWS,
- * P3D_FUSED_SMALL16, P3D_COMPACT_BLOCKS, P3D_COMPACT_EARLY, P3D_TEST_ID_LIMIT, P3D_NO_CHUNK_PRE) are read from the environment ONCE, at
+ * P3D_FUSED_SMALL16, P3D_COMPACT_BLOCKS, P3D_COMPACT_EARLY, P3D_TEST_ID_LIMIT, P3D_TEST_INDEX_LIMIT, P3D_NO_CHUNK_PRE) are read from the environment ONCE, at
  * the first call; this re-reads them.  Not to be called while another thread is inside the library. */
 int p3d_mc_reload_tuning(void);
 

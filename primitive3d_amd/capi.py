@@ -9,6 +9,7 @@ from ._build import capi_path
 
 P3D_F32, P3D_F16 = 0, 1
 P3D_OK = 0
+P3D_ERANGE = -2
 
 # every symbol include/p3d_mc.h declares
 SYMBOLS = ("p3d_mc_abi_version", "p3d_last_error", "p3d_mc_workspace_bytes", "p3d_mc_count",
@@ -21,11 +22,11 @@ class Slab(ctypes.Structure):
     """p3d_mc_slab (include/p3d_mc.h)."""
     _fields_ = [("halo_last_plane", c_int32), ("part", c_int32), ("vertex_id_base", c_int64),
                 ("halo_vertex_id_base", c_int64), ("x_origin", c_int64), ("split_plane", c_int64),
-                ("rank_counts", c_void_p), ("rank", c_int32)]
+                ("rank_counts", c_void_p), ("rank", c_int32), ("rank_counts_stride", c_int32)]
 
 
 class P3DError(RuntimeError):
-    pass
+    code = 0   # the P3D_E* value the call returned
 
 
 _LIB = None
@@ -72,7 +73,9 @@ def lib():
 
 def _check(rc, what):
     if rc != P3D_OK:
-        raise P3DError(f"{what} failed ({rc}): {lib().p3d_last_error().decode()}")
+        e = P3DError(f"{what} failed ({rc}): {lib().p3d_last_error().decode()}")
+        e.code = rc
+        raise e
 
 
 def workspace_bytes(rx, ry, rz) -> int:

@@ -455,7 +455,7 @@ struct FaceArgs {
     int halo_last;
     int64_t vid_base, halo_vid_base;
     const int64_t* rank_counts;  // optional: all-gathered V of all ranks on the device; the id bases are derived from it
-    int rank;
+    int rank, rank_stride;       // (rank r's count is rank_counts[r * rank_stride])
     int64_t tpp;           // tiles per plane
     int xw;                // planes per chunk (face_chunk_planes)
     int cpi;               // chunks per item (a single grid: all chunks)
@@ -939,9 +939,9 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     u32 b0 = (u32)a.vid_base, bhalo = (u32)a.halo_vid_base;
     if (a.rank_counts) {  // uniform: a handful of scalar loads
         int64_t acc = 0;
-        for (int r = 0; r < a.rank; ++r) acc += a.rank_counts[r];
+        for (int r = 0; r < a.rank; ++r) acc += a.rank_counts[(size_t)r * a.rank_stride];
         b0 = (u32)acc;
-        bhalo = (u32)(acc + a.rank_counts[a.rank]);
+        bhalo = (u32)(acc + a.rank_counts[(size_t)a.rank * a.rank_stride]);
     }
 
     // (32-bit index arithmetic: a 64-bit division costs more than a hundred instructions per wave)
@@ -1234,13 +1234,14 @@ int env_int(const char* name, int dflt) {
 // first call (no getenv in the per-call host path); -1 = "use the built-in rule".
 struct Tuning {
     int fused_blocks, fused_xt, fused_xt_tail, fused_tail_div, split_rows, small16, compact_blocks, compact_early,
-        test_id_limit, no_chunk_pre;
+        test_id_limit, no_chunk_pre, test_index_limit;
 };
 Tuning read_tuning() {
     return Tuning{env_int("P3D_FUSED_BLOCKS", 2048), env_int("P3D_FUSED_XT", -1), env_int("P3D_FUSED_XT_TAIL", -1),
                   env_int("P3D_FUSED_TAIL_DIV", 4), env_int("P3D_FUSED_SPLIT_ROWS", 1), env_int("P3D_FUSED_SMALL16", 1),
                   env_int("P3D_COMPACT_BLOCKS", 256), env_int("P3D_COMPACT_EARLY", 3),
-                  env_int("P3D_TEST_ID_LIMIT", 1 << 26), env_int("P3D_NO_CHUNK_PRE", 0)};
+                  env_int("P3D_TEST_ID_LIMIT", 1 << 26), env_int("P3D_NO_CHUNK_PRE", 0),
+                  env_int("P3D_TEST_INDEX_LIMIT", 0x7fffffff)};
 }
 Tuning g_tuning;
 std::once_flag g_tuning_once;
@@ -1490,7 +1491,8 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
     if (w.nb_f > 0 && capf > 0) {
         StageTimer tm(ST_EMIT_FACES, st);
         const FaceArgs a{2, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
-                         slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw, (int)w.cpi,
+                         slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0,
+                         (slab && slab->rank_counts_stride > 0) ? slab->rank_counts_stride : 1, w.tpp, w.xw, (int)w.cpi,
                          (const u32*)(ws + w.chunk_sum), nullptr, (const u32*)(ws + w.wave_off),
                          (const u32*)(ws + w.tile_tris), nullptr, nullptr, 0};
         const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr, 1u << 26, 1, nullptr};
@@ -1699,7 +1701,8 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         return P3D_OK;
     }
     const FaceArgs a{1, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
-                     slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0, w.tpp, w.xw, (int)w.cpi,
+                     slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0,
+                         (slab && slab->rank_counts_stride > 0) ? slab->rank_counts_stride : 1, w.tpp, w.xw, (int)w.cpi,
                      csum, cpre, woff, (const u32*)(ws + w.tile_tris), cursors, mb, seq};
     const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, (nparts - early) * kRegions, early,
                          nparts, part == 5 ? 0 : 1, csum, (int)w.nchunks, cursors, id_limit, 1, nullptr};
@@ -1751,7 +1754,7 @@ int fused_stack_impl(const T* grids, const Dims& d, const Ws& w, float thresh, c
                               nparts, 0, csum, (int)w.nchunks, cursors, id_limit, d.nitems, item_offsets};
         launch_count_walk(dim3((u32)(w.nchunks + cpe.nblocks)), st, bits, d, w, csum, woff, (u32*)(ws + w.tile_tris), cpre, cpe, hdr);
     }
-    const FaceArgs a{1, 0, 0, 0, nullptr, 0, w.tpp, w.xw, (int)w.cpi, csum, cpre, woff,
+    const FaceArgs a{1, 0, 0, 0, nullptr, 0, 1, w.tpp, w.xw, (int)w.cpi, csum, cpre, woff,
                      (const u32*)(ws + w.tile_tris), cursors, nullptr, 0};
     const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows,
                          (nparts - early) * kRegions * d.nitems, early, nparts, 0, csum, (int)w.nchunks, cursors, id_limit,
@@ -1810,7 +1813,9 @@ int p3d_mc_read_counts(const void* ws, int64_t* num_vertices, int64_t* num_faces
     *num_vertices = (int64_t)h[H_V];
     *num_faces = (int64_t)h[H_T];
     if (scratch_overflow) *scratch_overflow = (int32_t)(h[H_FLAGS] & 3ull);
-    if (h[H_V] > 0x7fffffffull || h[H_T] > 0x7fffffffull)
+    // (test hook: P3D_TEST_INDEX_LIMIT pretends the int32 limit is smaller, to reach the callers' handling of it)
+    const u64 index_limit = (u64)std::max(1, tuning().test_index_limit);
+    if (h[H_V] > index_limit || h[H_T] > index_limit)
         return fail(P3D_ERANGE, "vertex/face count exceeds int32 indexing%s");
     return P3D_OK;
 }

@@ -113,7 +113,9 @@ def marching_cubes_batched(density_grids, thresh: float, scale=None):
     The whole batch is ONE call of the native library (include/p3d_mc.h: p3d_mc_extract_fused_batched: one
     streaming launch, one counting launch and one face launch for all items).
     Returns (vertices [sumV,3] f32, faces [sumF,3] i32 with per-item LOCAL vertex ids,
-    vertex_offsets [B+1] i64, face_offsets [B+1] i64 -- all four on the device).
+    vertex_offsets [B+1] i64, face_offsets [B+1] i64 -- all four ON THE DEVICE, like the meshes: the call does not
+    synchronise; slicing with the offsets (`v[vo[b]:vo[b+1]]`) reads them back and so waits for the call's GPU work).
+    A batch whose total vertex or face count exceeds int32 is extracted item by item (the limit applies per item).
     """
     from . import capi
     if isinstance(density_grids, np.ndarray):
@@ -147,7 +149,14 @@ def marching_cubes_batched(density_grids, thresh: float, scale=None):
         f = torch.empty((capf, 3), dtype=torch.int32, device=dev)
         scratch = torch.empty((rows, 3), dtype=torch.float32, device=dev)
         capi.extract_fused_batched_raw(density_grids, thresh, lower, upper, ws, v, scratch, f, offs)
-        nv, nf, flags = capi.read_counts(ws, with_flags=True)
+        try:
+            nv, nf, flags = capi.read_counts(ws, with_flags=True)
+        except capi.P3DError as e:
+            if e.code != capi.P3D_ERANGE:
+                raise
+            # the TOTALS of the batch exceed int32 although face ids are local to an item: item by item, every item
+            # is checked against the limit on its own
+            break
         fitted = nv <= capv and nf <= capf and not flags
         if len(_BATCH_HINTS) >= 256 and key not in _BATCH_HINTS:
             _BATCH_HINTS.clear()

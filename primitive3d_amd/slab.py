@@ -56,8 +56,10 @@ class HipBackend:
         capv = self._cap if self._cap is not None else max(4096, rx * ry * rz // 16)
         self._verts = torch.empty((capv, 3), dtype=torch.float32, device=self.device)
         self._scratch = torch.empty((c.scratch_rows_for(capv), 3), dtype=torch.float32, device=self.device)
+        # rc: the all-gathered vertex counts on the device, [world] int64 or [world, k] with the counts in column 0
         self._mk = lambda part=0, split=0, vb=0, hb=0, rc=None, rank=0: c.Slab(
-            1 if halo else 0, part, vb, hb, x_origin, split, rc.data_ptr() if rc is not None else None, rank)
+            1 if halo else 0, part, vb, hb, x_origin, split, rc.data_ptr() if rc is not None else None, rank,
+            rc.stride(0) if rc is not None else 0)
 
     def begin_interior(self, grid, thresh, lower, upper, full_res, x_origin, halo, split):
         """Stream planes [0, split): they do not touch the halo plane, so this can run while it is in flight."""
@@ -78,8 +80,13 @@ class HipBackend:
         self._state = (grid, thresh, lower, upper, full_res, self._ws, None)
 
     def header_vertex_count(self):
-        """This rank's vertex count as a device tensor (the first int64 of the workspace): all-gather input."""
+        """This rank's vertex count as a device tensor (the first int64 of the workspace)."""
         return self._ws[:8].view(torch.int64)
+
+    def header_words(self):
+        """The first three int64 of the workspace header -- (V, unused here, flags) -- as a device tensor: the input of
+        the all-gather, so that every rank learns every rank's vertex count AND overflow flags."""
+        return self._ws[:24].view(torch.int64)
 
     def launch_finalize(self):
         """Part 4: face count + the first slices of the vertex compaction; V and F go to the host mailbox."""
@@ -96,10 +103,11 @@ class HipBackend:
         grid, thresh, lower, upper, full_res, ws, _ = self._state
         verts = self._verts
         nv, nf, over = c.read_counts(ws, with_flags=True)
-        if over & 2:
-            raise OverflowError("a vertex region of this slab numbered more than 2^26 vertices (include/p3d_mc.h, "
-                                "p3d_mc_read_counts bit 1): use more ranks / thinner slabs")
-        overflow = nv > verts.shape[0] or over
+        # bit 1: a vertex region numbered more than 2^26 vertices, its ids are ambiguous.  Not raised HERE: the other
+        # ranks would go on into the collectives and hang -- the orchestration spreads the flag to all ranks first
+        # (SlabExtractor.extract) and every rank raises.
+        self.id_overflow = bool(over & 2)
+        overflow = nv > verts.shape[0] or (over & 1)
         if overflow:
             verts = torch.empty((nv, 3), dtype=torch.float32, device=self.device)
             c.emit(grid, thresh, lower, upper, ws, verts, None, slab=self._slab, full_res=full_res)
@@ -134,7 +142,9 @@ class HipBackend:
             nv, nf, verts, overflow = self._read_totals()
             self._scratch = None
             self._copy_pending = False
-            if nf > capf:
+            if self.id_overflow:
+                pass   # (the caller raises; the ids are ambiguous, nothing to re-emit)
+            elif nf > capf:
                 faces = torch.empty((nf, 3), dtype=torch.int32, device=self.device)
                 c.emit(grid, thresh, lower, upper, ws, None, faces, slab=self._mk(0, 0, 0, 0, rank_counts, rank),
                        full_res=full_res)
@@ -210,7 +220,8 @@ class SlabResult:
     @property
     def vertex_base(self) -> int:
         if self._base is None:
-            self._base = int(self._rank_counts[:self._rank].sum()) if self._rank else 0
+            rc = self._rank_counts if self._rank_counts.dim() == 1 else self._rank_counts[:, 0]
+            self._base = int(rc[:self._rank].sum()) if self._rank else 0
         return self._base
 
     def __iter__(self):  # (vertices, faces) unpacking like the single-GPU call
@@ -279,6 +290,13 @@ class SlabExtractor:
         self._nv, self._nf, self._verts = nv, nf, verts
         return nv, nf
 
+    ID_OVERFLOW = ("a vertex region of the slab of rank %s numbered more than 2^26 vertices (include/p3d_mc.h, "
+                   "p3d_mc_read_counts bit 1): use more ranks / thinner slabs")
+
+    def id_overflow(self) -> bool:
+        """This rank's last extraction handed out ambiguous vertex ids (every rank must learn it: extract())."""
+        return bool(getattr(self.backend, "id_overflow", False))
+
     def records_send_buffer(self):
         return self.backend.export_first_plane_records() if self.rank > 0 else None
 
@@ -294,18 +312,32 @@ class SlabExtractor:
         faces = self.backend.faces(base, halo_base)
         return SlabResult(self._verts, faces, base, counts)
 
+    def _make_total_check(self, host, ev):
+        """The deferred check of ONE extraction (its own pinned copy of the gathered header words and its own event), as
+        a closure: a SlabResult keeps its own, whatever the extractor does afterwards."""
+        state = {"done": False, "error": None}
+
+        def check(wait: bool = True):
+            if not state["done"]:
+                if wait:
+                    ev.synchronize()
+                elif not ev.query():
+                    return
+                state["done"] = True
+                bad = [r for r in range(host.shape[0]) if int(host[r, 2]) & 2]
+                if bad:
+                    state["error"] = OverflowError(self.ID_OVERFLOW % bad)
+                elif int(host[:, 0].sum()) > 2 ** 31 - 1:
+                    state["error"] = OverflowError("global vertex count exceeds int32 face indices")
+            if state["error"] is not None:
+                raise state["error"]
+        return check
+
     def _check_pending_total(self, wait: bool = True):
-        pend = getattr(self, "_pending_total", None)
-        if pend is None:
-            return
-        host, ev = pend
-        if wait:
-            ev.synchronize()
-        elif not ev.query():
-            return
-        self._pending_total = None
-        if int(host.sum()) > 2 ** 31 - 1:
-            raise OverflowError("global vertex count exceeds int32 face indices")
+        check = getattr(self, "_pending_check", None)
+        if check is not None:
+            self._pending_check = None
+            check(wait)
 
     # -- the distributed call -----------------------------------------------------------------
     def extract(self, thresh, lower=None, upper=None) -> SlabResult:
@@ -347,11 +379,13 @@ class SlabExtractor:
             # bases from the gathered tensor)
             be = self.backend
             be.stream_rest(self.grid, float(thresh), list(lower), list(upper), self.shape, self.x0, self.has_halo)
-            rank_counts = torch.empty(self.world, dtype=torch.int64, device=self.grid.device)
+            # (V, -, flags) of every rank: the face kernel reads the counts with a stride of 3 (p3d_mc_slab), and every
+            # rank learns every rank's overflow flags with them
+            rank_counts = torch.empty((self.world, 3), dtype=torch.int64, device=self.grid.device)
             send_buf = self.records_send_buffer()  # (kept referenced until the transfer has completed)
             self._mark("last planes streamed + record export")
             pre_comm()
-            dist.all_gather_into_tensor(rank_counts, be.header_vertex_count())
+            dist.all_gather_into_tensor(rank_counts.view(-1), be.header_words())
             counts_ready = torch.cuda.Event() if self.grid.is_cuda else None
             if counts_ready is not None:
                 counts_ready.record()
@@ -371,7 +405,8 @@ class SlabExtractor:
             # (on a side stream, ordered only after the all-gather: inside the compute stream the 64-byte copy cost the
             #  stream ~10 us per extraction)
             self._check_pending_total()
-            host = torch.empty(self.world, dtype=torch.int64, pin_memory=True) if self.grid.is_cuda else None
+            host = torch.empty((self.world, 3), dtype=torch.int64, pin_memory=True) if self.grid.is_cuda else None
+            check = None
             if host is not None:
                 if getattr(self, "_guard_stream", None) is None:
                     self._guard_stream = torch.cuda.Stream(device=self.grid.device)
@@ -382,18 +417,26 @@ class SlabExtractor:
                     ev = torch.cuda.Event()
                     ev.record(gs)
                 rank_counts.record_stream(gs)
-                self._pending_total = (host, ev)
-            return SlabResult(self._verts, faces, rank=self.rank, rank_counts=rank_counts,
-                              check=self._check_pending_total)
+                check = self._make_total_check(host, ev)
+                self._pending_check = check
+            if self.id_overflow():
+                # this rank knows already; every collective of this extraction has been enqueued, and the other ranks
+                # raise from the gathered flags before their next one (the deferred check at the start of extract())
+                raise OverflowError(self.ID_OVERFLOW % self.rank)
+            return SlabResult(self._verts, faces, rank=self.rank, rank_counts=rank_counts, check=check)
         nv, nf = self.phase_extract(thresh, lower, upper)
-        mine = torch.tensor([nv, nf], dtype=torch.int64, device=self.grid.device)
+        mine = torch.tensor([nv, nf, 1 if self.id_overflow() else 0], dtype=torch.int64, device=self.grid.device)
         allc = [torch.empty_like(mine) for _ in range(self.world)]
         send_buf = self.records_send_buffer()
         pre_comm()
         dist.all_gather(allc, mine)
-        counts = [(int(c[0]), int(c[1])) for c in torch.stack(allc).cpu()]
+        gathered = torch.stack(allc).cpu()
+        counts = [(int(c[0]), int(c[1])) for c in gathered]
         for w in shift_to_prev(send_buf, self.records_recv_buffer()):
             w.wait()
+        bad = [r for r in range(self.world) if int(gathered[r, 2])]
+        if bad:   # every rank raises, after the collectives of this extraction: nobody is left waiting
+            raise OverflowError(self.ID_OVERFLOW % bad)
         return self.phase_faces(counts)
 
 
@@ -414,6 +457,8 @@ def extract_in_process(grid_full: torch.Tensor, world: int, thresh, lower=None, 
     for r in range(world - 1):  # phase A
         exs[r].halo_recv_buffer().copy_(exs[r + 1].halo_send_buffer())
     counts = [e.phase_extract(thresh, lower, upper) for e in exs]  # phase B
+    if any(e.id_overflow() for e in exs):
+        raise OverflowError(SlabExtractor.ID_OVERFLOW % [e.rank for e in exs if e.id_overflow()])
     for r in range(world - 1):  # phase C
         exs[r].records_recv_buffer().copy_(exs[r + 1].records_send_buffer())
     return [e.phase_faces(counts) for e in exs]  # phase D

@@ -192,6 +192,21 @@ def test_chunk_prefix_handoff_under_load(gpu, built, tuning_env, kind):
         assert torch.equal(key(v, f), h0)
 
 
+def test_batch_whose_totals_exceed_int32_goes_item_by_item(gpu, built, tuning_env):
+    """Face ids are local to an item, so only an ITEM is bound by int32 -- but the one-launch path reports the batch
+    totals through p3d_mc_read_counts, which refuses totals beyond int32 (P3D_ERANGE).  P3D_TEST_INDEX_LIMIT pretends
+    that limit is 6000: the batch (3 items of ~4400 faces) exceeds it, every item fits."""
+    grids = torch.from_numpy(np.random.default_rng(8).standard_normal((3, 9, 10, 20)).astype(np.float32))
+    counts = [oracle_count(grids[b].numpy(), 0.0) for b in range(3)]
+    assert max(c[1] for c in counts) < 6000 < sum(c[1] for c in counts)
+    tuning_env("P3D_TEST_INDEX_LIMIT", "6000")
+    v, f, vo, fo = built.marching_cubes_batched(grids.to(gpu), 0.0)
+    for b in range(3):
+        assert (int(vo[b + 1] - vo[b]), int(fo[b + 1] - fo[b])) == counts[b]
+        fb = f[fo[b]:fo[b + 1]]
+        assert int(fb.min()) >= 0 and int(fb.max()) < counts[b][0]
+
+
 def test_c5_32x256_fp16_full_batch(gpu, built):
     """BASELINE.json configs[4] at its stated size: 32 x 256^3 fp16 density grids through marching_cubes_batched.
     Every item: counts against the independent torch count + mesh properties; four items: the whole mesh (triangle

@@ -68,6 +68,16 @@ def test_distributed_extract_over_rccl(tmp_path, gpu, shape):
     _run_and_compare(tmp_path, min(8, torch.cuda.device_count()), shape, "nccl")
 
 
+@pytest.mark.parametrize("shape", [(61, 21, 150), (208, 40, 150)])
+def test_device_path_over_rccl_with_one_rank(tmp_path, gpu, shape):
+    """RCCL itself, executed on the one GPU of the test box: a `world_size = 1` process group of the "nccl" backend in a
+    spawned child, SlabExtractor.extract() through the DEVICE path -- `all_gather_into_tensor` of the three header words
+    straight out of the workspace, the side-stream int32 / overflow guard with its `record_stream`, the face launch
+    taking its id bases from the gathered tensor -- twice (the second call takes the size hints), result == the oracle's
+    mesh of the whole grid.  (Two ranks need two GPUs: the test above.)"""
+    _run_and_compare(tmp_path, 1, shape, "nccl")
+
+
 def _run_and_compare(tmp_path, world, shape, backend):
     from primitive3d_amd.fields import perlin_grid
     thresh, lower, upper = 0.02, [0.5, -1.0, 2.0], [3.0, 4.0, 9.0]

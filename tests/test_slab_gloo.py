@@ -102,6 +102,36 @@ def test_slab_orchestration_over_gloo(tmp_path, world, built):
     assert np.array_equal(hk, rk) and np.array_equal(hf, rf) and np.array_equal(hv, rv)
 
 
+def _overflow_worker(rank, world, port, out_dir, shape):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from primitive3d_amd.fields import perlin_grid
+    from primitive3d_amd.slab import SlabExtractor
+    be = OracleBackend()
+    be.id_overflow = rank == 1   # only ONE rank's slab reports ambiguous ids
+    ex = SlabExtractor(shape, rank, world, torch.device("cpu"), backend=be)
+    ex.fill_local(lambda x0, x1: perlin_grid(shape, period=10, seed=2, x0=x0, x1=x1))
+    try:
+        ex.extract(0.03)
+        outcome = "returned"
+    except OverflowError as e:
+        outcome = "OverflowError: " + str(e)
+    (Path(out_dir) / f"r{rank}.txt").write_text(outcome)
+    dist.barrier()   # (every rank gets here: none is stuck inside a collective of extract())
+    dist.destroy_process_group()
+
+
+def test_id_overflow_on_one_rank_raises_on_every_rank(tmp_path, built):
+    """One rank's local extraction reports an id-space overflow (include/p3d_mc.h, p3d_mc_read_counts bit 1).  It used
+    to raise on that rank alone, before the collectives: the other ranks then waited in the all-gather for ever.  The
+    flag now travels with the gathered counts and EVERY rank raises after the collectives."""
+    world, shape = 3, (13, 9, 20)
+    port = 29500 + (os.getpid() % 2000) + 17
+    mp.spawn(_overflow_worker, args=(world, port, str(tmp_path), shape), nprocs=world, join=True)
+    outcomes = [(tmp_path / f"r{r}.txt").read_text() for r in range(world)]
+    assert all(o.startswith("OverflowError") and "[1]" in o for o in outcomes), outcomes
+
+
 def test_slab_bounds():
     from primitive3d_amd.slab import slab_bounds
     assert slab_bounds(1024, 8) == [(i * 128, (i + 1) * 128) for i in range(8)]
