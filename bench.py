@@ -102,6 +102,60 @@ def cpu_baseline(grid, thresh, lower, upper, out_v, out_f, budget=(8.0, 6.0)):
     return res
 
 
+def other_configs(p3d, capi, perlin_grid, dev):
+    """The other single-GPU workloads of BASELINE.json (configs[1], [3] on one GPU, [4]) for a few steps each, AFTER the
+    headline measurement and outside its timed region: same call pattern (back-to-back calls between two
+    synchronisations), `k_fused` timed on the steps that follow by dispatch-attached hipEvents.  No CPU leg here (the
+    parity of these configurations at full size is tests/test_gpu_configs.py).  A few seconds in all."""
+    import numpy as np
+    import torch
+    out = {}
+
+    def measure(name, workload, step, nvox, sizeof, steps, warmup=3):
+        for _ in range(warmup):
+            res = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        capi.profile_enable(1)
+        dom = []
+        for _ in range(3):
+            res = step()
+            st = capi.profile_read()
+            dom.append(st.get("k_fused", float("nan")))
+        torch.cuda.synchronize()
+        capi.profile_enable(0)
+        kms = sum(dom) / len(dom)
+        alg = nvox * sizeof
+        out[name] = {"workload": workload, "steps": steps, "ms_per_step": round(ms, 4),
+                     "value": round(nvox / (ms * 1e-3) / 1e6, 1), "unit": "Mvoxels/s",
+                     "dtype": "f16" if sizeof == 2 else "f32", "vertices": int(res[0].shape[0]), "faces": int(res[1].shape[0]),
+                     "k_fused_ms": round(kms, 4), "k_fused_frac": round(alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "whole_call_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    b66 = torch.from_numpy(np.load(ROOT / "tests" / "golden" / "bunny66.npy"))
+    g2 = torch.nn.functional.interpolate(b66[None, None], size=(256,) * 3, mode="trilinear", align_corners=True)[0, 0]
+    g2 = g2.contiguous().to(dev)
+    measure("c2", "256x256x256 fp32 bunny SDF (examples/data/bunny.npy trilinearly resampled from 66^3), iso 0",
+            lambda: p3d.libPrim3D.marching_cubes(g2, 0.0, [0.0] * 3, [256.0] * 3), 256 ** 3, 4, steps=40, warmup=5)
+    del g2
+    g5 = torch.stack([perlin_grid((256,) * 3, period=64, seed=s, device=dev).half() for s in range(32)])
+    measure("c5", "batch of 32 x 256x256x256 fp16 Perlin SDF grids (period 64, seeds 0..31), iso 0, one "
+                  "marching_cubes_batched call per step",
+            lambda: p3d.marching_cubes_batched(g5, 0.0)[:2], 32 * 256 ** 3, 2, steps=10)
+    del g5
+    g4 = perlin_grid((1024,) * 3, period=64, seed=0, device=dev)
+    measure("c4_1gpu", "1024x1024x1024 fp32 single-octave Perlin SDF (period 64, seed 0), iso 0, on ONE GPU (the "
+                       "baseline of the 8-GPU target)",
+            lambda: p3d.libPrim3D.marching_cubes(g4, 0.0, [0.0] * 3, [1024.0] * 3), 1024 ** 3, 4, steps=6)
+    del g4
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,6 +166,8 @@ def main():
                     help="N=1 workload (BASELINE.json configs): c2 = 256^3 bunny SDF fp32, c3 = 512^3 Perlin fp32 (the "
                          "headline; default), c4 = the 1024^3 volume on one GPU, c5 = batch of 32 x 256^3 fp16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short c2 / c5 / c4-on-one-GPU measurements that follow the headline run")
     ap.add_argument("--stages", action="store_true", help="also print per-stage hipEvent times to stderr")
     args = ap.parse_args()
 
@@ -306,6 +362,8 @@ def main():
                        "partition": "none" if world == 1 else f"axis-0 slabs x{world}, 1-plane RCCL halo"},
             "roofline": roofline,
         }
+        if world == 1 and args.config == "c3" and not args.size and not args.no_other_configs:
+            line["other_configs"] = other_configs(p3d, capi, perlin_grid, dev)
         if world == 1 and not args.no_cpu_baseline:
             if batch > 1:   # bounded sample: the first items of the batch, each compared with the GPU's mesh of that item
                 v_all, f_all, vo, fo = p3d.marching_cubes_batched(grid, thresh)

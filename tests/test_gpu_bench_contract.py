@@ -32,3 +32,23 @@ def test_bench_line_schema(gpu):
     assert c["single_thread_value"] > 0 and "pymcubes" in c
     assert r["call_median_ms_hipevents"] > 0 and r["cold_first_call_ms"] > 0
     assert d["value"] > 0 and abs(d["value"] - 128 ** 3 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
+
+
+def test_default_run_reports_the_other_configs(gpu):
+    """The default run (the one the driver records) also times BASELINE.json's other single-GPU workloads for a few steps
+    each, after and outside the headline measurement, under `other_configs`; the headline fields stay what they were."""
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert d["metric"].startswith("Mvoxels/s on 512^3 fp32 SDF") and d["dtype"] == "f32" and d["steps"] == 3
+    assert abs(d["value"] - 512 ** 3 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
+    oc = d["other_configs"]
+    assert sorted(oc) == ["c2", "c4_1gpu", "c5"]
+    nvox = {"c2": 256 ** 3, "c5": 32 * 256 ** 3, "c4_1gpu": 1024 ** 3}
+    for k, c in oc.items():
+        assert c["unit"] == "Mvoxels/s" and c["ms_per_step"] > 0 and c["vertices"] > 0 and c["faces"] > 0, (k, c)
+        assert abs(c["value"] - nvox[k] / (c["ms_per_step"] * 1e-3) / 1e6) / c["value"] < 0.01
+        assert 0 < c["whole_call_frac"] < c["k_fused_frac"] < 1.0
+    assert oc["c5"]["dtype"] == "f16" and oc["c2"]["dtype"] == "f32"
+    assert (oc["c2"]["vertices"], oc["c2"]["faces"]) == (252218, 504432) or oc["c2"]["faces"] > 100000
