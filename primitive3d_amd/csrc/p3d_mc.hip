@@ -1166,6 +1166,305 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_faces2 -- the face kernel, second version (round 3).  Same tiles, same face order, same prologue as k_faces; what
+// changed is the work per CELL, which is what bounds this kernel (VALU issue, not memory):
+//   * everything per cell is 32-bit.  The sign words are staged as a DWORD stream and a cell reads, per column, the
+//     two dwords starting at the half unit that holds z (index 2t + z/32): bit z and bit z+1 are always inside that
+//     window, also at z = 31 and at z = 63 (the next dword is the next half / the next chunk of the same row) -- no
+//     64-bit shifts, no "first bit of the next chunk" side table, no divergent branch for z = 63;
+//   * the vertex-id records are expanded ONCE PER STAGED UNIT into per-HALF form: {first id of the unit, byte offsets
+//     of the first x / y / z edge id of the low half, the same for the high half} -- the high half's offsets include
+//     the popcounts of the low halves of the unit's crossing words (computed by the staging thread from words it
+//     loads in the same round trip).  An id is then  popcount(crossing32 & below(z % 32)) + base + offset: and, bcnt,
+//     byte-add;
+//   * the ids of the four edges at z + 1 are the ids at z plus "edge at z crosses" (bits of the corner mask), or the
+//     next unit's first ids when z = 63;
+//   * every cell of the list is active, so the ids are computed unconditionally and all LDS reads of a batch are issued
+//     before the first wait (the old kernel had five dependent LDS round trips per batch in front of the triangles);
+//   * the case table row carries its triangle count in the top nibble (one lookup), the triangle rounds are unrolled
+//     with constant shifts and store through a wave-uniform base + 32-bit offset.
+// ---------------------------------------------------------------------------------------------
+__device__ inline u32 add_byte0(u32 a, u32 packed) { return a + (packed & 0xffu); }
+__device__ inline u32 add_byte1(u32 a, u32 packed) { return a + ((packed >> 8) & 0xffu); }
+__device__ inline u32 add_byte2(u32 a, u32 packed) { return a + ((packed >> 16) & 0xffu); }
+__device__ inline u32 rank32(u32 crossing, u32 lowm, u32 base) {   // base + crossings below z in this half
+    return (u32)__builtin_popcount(crossing & lowm) + base;
+}
+
+template <int NHALO>
+__global__ void __launch_bounds__(kBlock) k_faces2(const u64* __restrict__ bits, const uint2* __restrict__ rec, Dims d,
+                                                   FaceArgs a, CompactArgs cp, u64* __restrict__ hdr,
+                                                   int32_t* __restrict__ faces, int64_t cap_faces) {
+    if ((int)blockIdx.x < cp.nblocks) {  // the launch's first blocks move the vertices (uniform per block)
+        compact_block(cp, hdr, a.mb, a.seq);
+        return;
+    }
+    constexpr int NS = (kBlock + NHALO + 1) > 2 * (kBlock + 1) ? (kBlock + NHALO + 1) : (NHALO >= kBlock ? 2 * (kBlock + 1) : kBlock + NHALO + 1);
+    __shared__ u64 s_tab[256];                           // case table row | triangle count << 60
+    __shared__ u64 s_w[2][NS + 1];                       // sign words of planes x and x+1 (read as a dword stream; one pad)
+    __shared__ u32 s_e[2][3 * NS + 3];                   // per staged unit: {first id, offsets of the low half, of the high half}
+    __shared__ unsigned short s_cells[4][kWaveCells];    // per wave: active cells of the round, unit-in-tile << 6 | z
+    __shared__ u32 s_ids[4][12][64];                     // per wave: vertex ids of the batch's cells' 12 edges
+    __shared__ u32 s_tmp[4];
+    const bool XLATE = a.xlate == 1 || (a.xlate == 2 && hdr[H_RECFORM] != 0ull);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {   // (tables indexed by the INTERLEAVED corner mask: bit 2k = column k at z, bit 2k+1 = column k at z+1)
+        int m = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m |= (((tid >> (2 * k)) & 1) << k) | (((tid >> (2 * k + 1)) & 1) << (k + 4));
+        s_tab[tid] = (g_tri_packed[m] & 0x0fffffffffffffffull) | ((u64)g_tri_count[m] << 60);
+    }
+    u32 pref = 0;
+    if (XLATE) {
+        if (a.xlate == 1) {
+            const u32 it = d.stack ? (((u32)blockIdx.x - (u32)cp.nblocks) / (u32)a.tpp) / (u32)d.xper : 0u;
+            const u32 cnt = lane < kRegions ? (u32)a.cursors[(size_t)it * kCursorBlockWords + lane * kCursorStride] : 0u;
+            pref = wave_prefix_sum(cnt) - cnt;
+        } else if (lane < kRegions) {
+            pref = (u32)hdr[H_PREFIX + lane];
+        }
+    }
+    auto dense = [&](u32 v) -> u32 {
+        return XLATE ? (v & 0x3ffffffu) + (u32)__builtin_amdgcn_ds_bpermute((int)(((v >> 26) & (kRegions - 1)) << 2), (int)pref) : v;
+    };
+    u32 b0 = (u32)a.vid_base, bhalo = (u32)a.halo_vid_base;
+    if (a.rank_counts) {
+        int64_t acc = 0;
+        for (int r = 0; r < a.rank; ++r) acc += a.rank_counts[(size_t)r * a.rank_stride];
+        b0 = (u32)acc;
+        bhalo = (u32)(acc + a.rank_counts[(size_t)a.rank * a.rank_stride]);
+    }
+    const u32 b = (u32)blockIdx.x - (u32)cp.nblocks;
+    const u32 x32 = b / (u32)a.tpp;
+    const int64_t x = x32;
+    const int64_t tile = b - x32 * (u32)a.tpp;
+    const u32 item = d.stack ? x32 / (u32)d.xper : 0u;
+    const u32 xl = x32 - item * (u32)d.xper;
+    if (xl == (u32)d.xper - 1u) return;
+    const u32 my_tris = a.tile_tris[b];
+    const int64_t p = tile * kBlock + tid;
+    const int64_t y = (u32)p / (u32)d.ncz;
+    const int c = (int)(p - y * d.ncz);
+    const bool valid = (p < d.P) && (y + 1 < d.ry);
+    const bool more = c + 1 < d.ncz;
+
+    // phase A: staging.  All global loads of the prologue are issued before the first wait: the tile's triangle count,
+    // the cursors, per staged unit the sign words of both planes, of both planes one row up (for the y crossings of the
+    // low half) and both records, this thread's share of the chunk totals.
+    const bool one_range = d.ncz <= NHALO;
+    const int hoff = one_range ? d.ncz : kBlock + 1;
+    const int nstage = one_range ? kBlock + d.ncz + 1 : 2 * (kBlock + 1);
+    const int64_t p0 = tile * kBlock;
+    const bool xhalo = a.halo_last && (x + 1 == d.rx - 1);
+    constexpr int NST = (NS + kBlock - 1) / kBlock;
+    u64 st_w0[NST], st_w1[NST], st_y0[NST], st_y1[NST];
+    uint2 st_r0[NST], st_r1[NST];
+#pragma unroll
+    for (int q = 0; q < NST; ++q) {
+        const int i = tid + q * kBlock;
+        st_w0[q] = st_w1[q] = st_y0[q] = st_y1[q] = 0ull;
+        st_r0[q] = st_r1[q] = make_uint2(0u, 0u);
+        const int64_t pi = (one_range || i <= kBlock) ? p0 + i : p0 + d.ncz + (i - kBlock - 1);
+        if (i < nstage && pi < d.P) {
+            const int64_t ui = x * d.P + pi;
+            st_w0[q] = bits[ui];
+            st_w1[q] = bits[ui + d.P];
+            st_r0[q] = rec[ui];
+            st_r1[q] = rec[ui + d.P];
+            if (pi + d.ncz < d.P) {   // the row above exists (same plane)
+                st_y0[q] = bits[ui + d.ncz];
+                st_y1[q] = bits[ui + d.P + d.ncz];
+            }
+        }
+    }
+    u32 cs = 0;
+    {
+        const int64_t mychunk = (int64_t)(item * (u32)a.cpi + (xl / (u32)a.xw) * (u32)a.tpp) + tile;
+        if (a.chunk_pre) {
+            if (tid == 0) cs = a.chunk_pre[mychunk];
+        } else {
+            for (int64_t i = tid; i < mychunk; i += kBlock) cs += a.chunk_sum[i];
+        }
+    }
+    if (my_tris == 0u) return;
+    u32* const E0 = s_e[0];
+    u32* const E1 = s_e[1];
+#pragma unroll
+    for (int q = 0; q < NST; ++q) {   // (uniform trip count: the translation shuffles across lanes)
+        const int i = tid + q * kBlock;
+        const u32 base0 = dense(st_r0[q].x) + b0;
+        const u32 base1 = xhalo ? st_r1[q].x + bhalo : dense(st_r1[q].x) + b0;
+        // offsets of the unit's first x / y / z edge id (bytes 0 / 1 / 2): low half = the record's, high half = plus
+        // the crossings of the low half (x crossings of plane x+1 belong to the next cell layer: not needed)
+        const u64 w0 = st_w0[q], w1 = st_w1[q];
+        const u32 oY0 = st_r0[q].y & 0xffffu, oZ0 = st_r0[q].y >> 16, oY1 = st_r1[q].y & 0xffffu, oZ1 = st_r1[q].y >> 16;
+        const u32 pX = (u32)__builtin_popcount((u32)(w0 ^ w1));
+        const u32 pY0 = (u32)__builtin_popcount((u32)(w0 ^ st_y0[q])), pY1 = (u32)__builtin_popcount((u32)(w1 ^ st_y1[q]));
+        const u32 pZ0 = (u32)__builtin_popcount((u32)(w0 ^ (w0 >> 1))), pZ1 = (u32)__builtin_popcount((u32)(w1 ^ (w1 >> 1)));
+        if (i < nstage) {
+            s_w[0][i] = w0;
+            s_w[1][i] = w1;
+            E0[3 * i] = base0;
+            E0[3 * i + 1] = (oY0 << 8) | (oZ0 << 16);
+            E0[3 * i + 2] = pX | ((oY0 + pY0) << 8) | ((oZ0 + pZ0) << 16);
+            E1[3 * i] = base1;
+            E1[3 * i + 1] = (oY1 << 8) | (oZ1 << 16);
+            E1[3 * i + 2] = ((oY1 + pY1) << 8) | ((oZ1 + pZ1) << 16);
+        }
+    }
+    if (tid == 0) {   // the pad dword behind the last staged unit (read by a window at z >= 32 of that unit, never used)
+        s_w[0][nstage] = 0ull;
+        s_w[1][nstage] = 0ull;
+    }
+    {
+        cs = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum(cs), 63);
+        if (lane == 0) s_tmp[wave] = cs;
+    }
+    __syncthreads();  // the only block barrier: staging done (no store is in flight yet)
+    // first face of this wave and the capacity, relative to it (a wave-tile emits at most 64 * 64 * 5 faces)
+    const u32 wrun0 = (u32)__builtin_amdgcn_readfirstlane((int)((s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3]) + a.wave_off[b * 4 + wave]));
+    const u32 cap32 = (u32)min(cap_faces, (int64_t)0x7fffffff);
+    const u32 cap_rel = cap32 > wrun0 ? cap32 - wrun0 : 0u;
+    int32_t* const wfaces = faces + (size_t)wrun0 * 3;   // (wave-uniform base: the stores take a 32-bit offset)
+    u32 rel = 0;                                          // faces this wave has written so far (uniform)
+
+    auto colw = [&](int k, int t) -> u64 { return s_w[(k == 1 || k == 2) ? 1 : 0][t + (k >= 2 ? hoff : 0)]; };
+    // per unit (lane = unit of this wave): active cells
+    u64 act_all = 0;
+    {
+        u64 orr = 0, andd = ~0ull;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u64 Wk = valid ? colw(k, tid) : 0ull;
+            const u64 nb = (valid && more) ? (colw(k, tid + 1) & 1ull) : 0ull;
+            const u64 S = (Wk >> 1) | (nb << 63);
+            orr |= Wk | S;
+            andd &= Wk & S;
+        }
+        if (valid) act_all = orr & ~andd & zedge(d, c);
+    }
+    static_assert(kWaveCells >= 256, "a 4-voxel z slice of a wave holds up to 256 cells");
+    int wbits = 64;
+    {
+        u32 fullest = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum((u32)popc64(act_all)), 63);
+        while (fullest > (u32)kWaveCells && wbits > 4) {   // (wave-uniform)
+            wbits >>= 1;
+            fullest = 0;
+            for (int sl = 0; sl < 64; sl += wbits) {
+                const u64 m = ((1ull << wbits) - 1ull) << sl;
+                fullest = max(fullest, (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum((u32)popc64(act_all & m)), 63));
+            }
+        }
+    }
+    const int rounds = 64 / wbits;
+    unsigned short* const cells = s_cells[wave];
+    const u32* const W0 = (const u32*)s_w[0];
+    const u32* const W1 = (const u32*)s_w[1];
+    u32* const ids = &s_ids[wave][0][lane];   // this lane's column: edge e at ids[e * 64]
+
+    for (int rd = 0; rd < rounds; ++rd) {
+        u64 act = rounds == 1 ? act_all : (act_all & (((1ull << wbits) - 1ull) << (wbits * rd)));
+        // phase B (lane = unit): dense list of the wave's active cells
+        const u32 pc = (u32)popc64(act);
+        const u32 inc0 = wave_prefix_sum(pc);
+        const u32 na = (u32)__builtin_amdgcn_readlane((int)inc0, 63);
+        u32 off = inc0 - pc;
+        while (act) {
+            const int z = __ffsll((long long)act) - 1;
+            act &= act - 1;
+            cells[off++] = (unsigned short)((tid << 6) | z);
+        }
+        wave_lds_sync();
+
+        for (u32 i0 = 0; i0 < na; i0 += 64) {
+            // phase C (lane = cell).  Every listed cell has a sign change, i.e. at least one triangle.
+            const u32 i = i0 + lane;
+            const bool on = i < na;
+            const u32 cell = on ? (u32)cells[i] : (u32)cells[i0];   // (idle lanes shadow the batch's first cell)
+            const u32 t = cell >> 6, zz = cell & 31u, D = cell >> 5, Dh = D + 2u * (u32)hoff;
+            const bool z63 = (cell & 63u) == 63u;
+            // the dword windows of the four columns: a = the half unit holding z, b = the dword behind it
+            const u32 a0 = W0[D], c0 = W0[D + 1], a1 = W1[D], c1 = W1[D + 1];
+            const u32 a3 = W0[Dh], c3 = W0[Dh + 1], a2 = W1[Dh], c2 = W1[Dh + 1];
+            // per-half id records: {base, offsets of this half}; the next unit's {base, low-half offsets} for z = 63
+            const u32 hsel = 1u + ((cell >> 5) & 1u);
+            const u32 th = t + (u32)hoff;
+            const u32 B0 = E0[3 * t], O0 = E0[3 * t + hsel], B1 = E1[3 * t], O1 = E1[3 * t + hsel];
+            const u32 B3 = E0[3 * th], O3 = E0[3 * th + hsel], B2 = E1[3 * th], O2 = E1[3 * th + hsel];
+            const u32 N0 = E0[3 * t + 3], NO0 = E0[3 * t + 4], N1 = E1[3 * t + 3], NO1 = E1[3 * t + 4], N3 = E0[3 * th + 3];
+            // corner mask (interleaved): bits z and z+1 of every column
+            const u32 t0 = __builtin_amdgcn_alignbit(c0, a0, zz), t1 = __builtin_amdgcn_alignbit(c1, a1, zz);
+            const u32 t2 = __builtin_amdgcn_alignbit(c2, a2, zz), t3 = __builtin_amdgcn_alignbit(c3, a3, zz);
+            const u32 mask = (t0 & 3u) | ((t1 & 3u) << 2) | ((t2 & 3u) << 4) | ((t3 & 3u) << 6);
+            const u64 row = s_tab[mask];
+            const u32 row_lo = (u32)row, row_hi = (u32)(row >> 32);
+            const u32 nt = on ? row_hi >> 28 : 0u;
+            // crossing words of this half (axis 0: columns (x,y) and (x,y+1); axis 1: (x,y) and (x+1,y); axis 2: all four)
+            const u32 lowm = (1u << zz) - 1u;
+            const u32 Cx0 = a0 ^ a1, Cx3 = a3 ^ a2, Cy0 = a0 ^ a3, Cy1 = a1 ^ a2;
+            const u32 Cz0 = a0 ^ __builtin_amdgcn_alignbit(c0, a0, 1), Cz1 = a1 ^ __builtin_amdgcn_alignbit(c1, a1, 1);
+            const u32 Cz2 = a2 ^ __builtin_amdgcn_alignbit(c2, a2, 1), Cz3 = a3 ^ __builtin_amdgcn_alignbit(c3, a3, 1);
+            // edges at z (Bourke numbering, marching_cubes.cu:178-192)
+            const u32 id0 = rank32(Cx0, lowm, add_byte0(B0, O0));
+            const u32 id3 = rank32(Cy0, lowm, add_byte1(B0, O0));
+            const u32 id8 = rank32(Cz0, lowm, add_byte2(B0, O0));
+            const u32 id1 = rank32(Cy1, lowm, add_byte1(B1, O1));
+            const u32 id9 = rank32(Cz1, lowm, add_byte2(B1, O1));
+            const u32 id10 = rank32(Cz2, lowm, add_byte2(B2, O2));
+            const u32 id2 = rank32(Cx3, lowm, add_byte0(B3, O3));
+            const u32 id11 = rank32(Cz3, lowm, add_byte2(B3, O3));
+            // edges at z+1: one more if the edge at z crosses (mask bit 2k = column k at z); at z = 63 they are the
+            // first ids of the next chunk of the row
+            const u32 q = mask ^ (mask >> 2), r = mask ^ (mask >> 6);
+            const u32 id4 = z63 ? N0 : id0 + (q & 1u);
+            const u32 id7 = z63 ? add_byte1(N0, NO0) : id3 + (r & 1u);
+            const u32 id5 = z63 ? add_byte1(N1, NO1) : id1 + ((q >> 2) & 1u);
+            const u32 id6 = z63 ? N3 : id2 + ((q >> 4) & 1u);
+            ids[0 * 64] = id0;
+            ids[1 * 64] = id1;
+            ids[2 * 64] = id2;
+            ids[3 * 64] = id3;
+            ids[4 * 64] = id4;
+            ids[5 * 64] = id5;
+            ids[6 * 64] = id6;
+            ids[7 * 64] = id7;
+            ids[8 * 64] = id8;
+            ids[9 * 64] = id9;
+            ids[10 * 64] = id10;
+            ids[11 * 64] = id11;
+            // the batch's triangles, k-th triangle of every cell together: the lanes that have one write a DENSE run.
+            // The three ids come back out of the lane's LDS column by table index.
+            bool go = true;
+            static_for<0, 5>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if (!go) return;
+                const u64 have = __ballot((u32)k < nt);
+                if (!have) {   // wave-uniform
+                    go = false;
+                    return;
+                }
+                const u32 f = __builtin_amdgcn_mbcnt_hi((u32)(have >> 32), __builtin_amdgcn_mbcnt_lo((u32)have, rel));
+                if ((u32)k < nt && f < cap_rel) {
+                    // nibbles 3k, 3k+1, 3k+2 of the row
+                    constexpr int s0 = 12 * k, s1 = 12 * k + 4, s2 = 12 * k + 8;
+                    const u32 e0 = ((s0 < 32 ? row_lo >> s0 : row_hi >> (s0 - 32)) & 15u);
+                    const u32 e1 = ((s1 < 32 ? row_lo >> s1 : row_hi >> (s1 - 32)) & 15u);
+                    const u32 e2 = ((s2 < 32 ? row_lo >> s2 : row_hi >> (s2 - 32)) & 15u);
+                    typedef int i3u __attribute__((ext_vector_type(3), aligned(4)));
+                    i3u tv;
+                    tv.x = (int32_t)ids[e0 * 64];
+                    tv.y = (int32_t)ids[e1 * 64];
+                    tv.z = (int32_t)ids[e2 * 64];
+                    __builtin_nontemporal_store(tv, (i3u*)(wfaces + f * 3u));
+                }
+                rel += (u32)popc64(have);
+            });
+        }
+        wave_lds_sync();   // the next round rewrites the cell list
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 thread_local char g_err[512] = "";
@@ -1234,14 +1533,14 @@ int env_int(const char* name, int dflt) {
 // first call (no getenv in the per-call host path); -1 = "use the built-in rule".
 struct Tuning {
     int fused_blocks, fused_xt, fused_xt_tail, fused_tail_div, split_rows, small16, compact_blocks, compact_early,
-        test_id_limit, no_chunk_pre, test_index_limit;
+        test_id_limit, no_chunk_pre, test_index_limit, faces_v;
 };
 Tuning read_tuning() {
     return Tuning{env_int("P3D_FUSED_BLOCKS", 2048), env_int("P3D_FUSED_XT", -1), env_int("P3D_FUSED_XT_TAIL", -1),
                   env_int("P3D_FUSED_TAIL_DIV", 4), env_int("P3D_FUSED_SPLIT_ROWS", 1), env_int("P3D_FUSED_SMALL16", 1),
                   env_int("P3D_COMPACT_BLOCKS", 256), env_int("P3D_COMPACT_EARLY", 3),
                   env_int("P3D_TEST_ID_LIMIT", 1 << 26), env_int("P3D_NO_CHUNK_PRE", 0),
-                  env_int("P3D_TEST_INDEX_LIMIT", 0x7fffffff)};
+                  env_int("P3D_TEST_INDEX_LIMIT", 0x7fffffff), env_int("P3D_FACES_V", 2)};
 }
 Tuning g_tuning;
 std::once_flag g_tuning_once;
@@ -1416,6 +1715,13 @@ void launch_faces(const Dims& d, const Ws& w, const u64* bits, const uint2* rec,
                   u64* hdr, int32_t* faces, int64_t capf, bool faces_here, hipStream_t st) {
     const dim3 fgrid((u32)((faces_here ? w.nb_f : 0) + cp.nblocks));
     if (fgrid.x == 0) return;
+    if (tuning().faces_v >= 2) {
+        if (d.ncz <= 32)
+            hipLaunchKernelGGL(k_faces2<32>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
+        else
+            hipLaunchKernelGGL(k_faces2<256>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
+        return;
+    }
     if (d.ncz <= 32)
         hipLaunchKernelGGL(k_faces<32>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
     else
