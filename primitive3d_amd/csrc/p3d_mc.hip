@@ -184,6 +184,37 @@ __device__ inline void write_lane2(int& lo, int& hi, u64 m) {
         : "s"((int)(u32)m), "s"((int)(u32)(m >> 32)), "n"(J)
         : "vcc");
 }
+// Four units at a time: the four compares first, then the eight v_writelane -- every v_writelane then reads an SGPR
+// pair written at least three VALU instructions earlier, so the hazard above needs no wait state at all (one
+// instruction slot per unit saved: the 32 s_nop of a plane cost as much issue time as 32 vector instructions).
+// sign word of unit J+q = (v_q > thresh) over the 64 lanes (ordered compare: NaN -> 0, marching_cubes.cu:25).
+#ifndef P3D_WL_GROUP
+#define P3D_WL_GROUP 1   // dev: 4 = grouped compares (no s_nop)
+#endif
+template <int J>
+__device__ inline void cmp_write_lane4(int& lo, int& hi, float v0, float v1, float v2, float v3, float thresh) {
+    u64 m0, m1, m2, m3;
+    asm("v_cmp_gt_f32_e64 %0, %4, %8\n\t"
+        "v_cmp_gt_f32_e64 %1, %5, %8\n\t"
+        "v_cmp_gt_f32_e64 %2, %6, %8\n\t"
+        "v_cmp_gt_f32_e64 %3, %7, %8"
+        : "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+        : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(thresh));
+    // (the first v_writelane reads the pair written by the FIRST compare, three instructions back; the last compare's
+    //  pair is read six instructions later)
+    asm("v_writelane_b32 %0, %2, %10\n\t"
+        "v_writelane_b32 %1, %3, %10\n\t"
+        "v_writelane_b32 %0, %4, %11\n\t"
+        "v_writelane_b32 %1, %5, %11\n\t"
+        "v_writelane_b32 %0, %6, %12\n\t"
+        "v_writelane_b32 %1, %7, %12\n\t"
+        "v_writelane_b32 %0, %8, %13\n\t"
+        "v_writelane_b32 %1, %9, %13"
+        : "+v"(lo), "+v"(hi)
+        : "s"((int)(u32)m0), "s"((int)(u32)(m0 >> 32)), "s"((int)(u32)m1), "s"((int)(u32)(m1 >> 32)), "s"((int)(u32)m2),
+          "s"((int)(u32)(m2 >> 32)), "s"((int)(u32)m3), "s"((int)(u32)(m3 >> 32)), "n"(J), "n"(J + 1), "n"(J + 2),
+          "n"(J + 3));
+}
 
 __device__ inline float load_f32(const float* p) { return *p; }
 __device__ inline float load_f32(const __half* p) { return __half2float(*p); }
@@ -1191,6 +1222,12 @@ __device__ inline u32 rank32(u32 crossing, u32 lowm, u32 base) {   // base + cro
     return (u32)__builtin_popcount(crossing & lowm) + base;
 }
 
+template <int N>
+__device__ inline u32 row_nibble(u32 lo, u32 hi) {   // nibble N of the 64-bit table row (lo, hi)
+    if constexpr (N < 8) return (lo >> (4 * N)) & 15u;
+    else return (hi >> (4 * (N - 8))) & 15u;
+}
+
 template <int NHALO>
 __global__ void __launch_bounds__(kBlock) k_faces2(const u64* __restrict__ bits, const uint2* __restrict__ rec, Dims d,
                                                    FaceArgs a, CompactArgs cp, u64* __restrict__ hdr,
@@ -1446,10 +1483,8 @@ __global__ void __launch_bounds__(kBlock) k_faces2(const u64* __restrict__ bits,
                 const u32 f = __builtin_amdgcn_mbcnt_hi((u32)(have >> 32), __builtin_amdgcn_mbcnt_lo((u32)have, rel));
                 if ((u32)k < nt && f < cap_rel) {
                     // nibbles 3k, 3k+1, 3k+2 of the row
-                    constexpr int s0 = 12 * k, s1 = 12 * k + 4, s2 = 12 * k + 8;
-                    const u32 e0 = ((s0 < 32 ? row_lo >> s0 : row_hi >> (s0 - 32)) & 15u);
-                    const u32 e1 = ((s1 < 32 ? row_lo >> s1 : row_hi >> (s1 - 32)) & 15u);
-                    const u32 e2 = ((s2 < 32 ? row_lo >> s2 : row_hi >> (s2 - 32)) & 15u);
+                    const u32 e0 = row_nibble<3 * k>(row_lo, row_hi), e1 = row_nibble<3 * k + 1>(row_lo, row_hi);
+                    const u32 e2 = row_nibble<3 * k + 2>(row_lo, row_hi);
                     typedef int i3u __attribute__((ext_vector_type(3), aligned(4)));
                     i3u tv;
                     tv.x = (int32_t)ids[e0 * 64];
