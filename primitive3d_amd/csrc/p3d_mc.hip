@@ -48,6 +48,25 @@ typedef unsigned int u32;
 __device__ const u64 g_tri_packed[256] = {P3D_TRI_TABLE_PACKED};
 __device__ const unsigned char g_tri_count[256] = {P3D_TRI_COUNT};
 
+// The same table for k_faces2: indexed by the INTERLEAVED corner mask (bit 2k = column k at z, bit 2k+1 = column k at
+// z+1 -- what one shift per column yields; the reference's mask, marching_cubes.cu:49-57, has bits 0-3 at z and 4-7 at
+// z+1: a fixed permutation of the index), with the row's triangle count in the top nibble (a row uses 15 nibbles).
+struct TriRows {
+    u64 r[256];
+};
+constexpr TriRows make_interleaved_rows() {
+    constexpr u64 packed[256] = {P3D_TRI_TABLE_PACKED};
+    constexpr unsigned char count[256] = {P3D_TRI_COUNT};
+    TriRows t{};
+    for (int i = 0; i < 256; ++i) {
+        int m = 0;
+        for (int k = 0; k < 4; ++k) m |= (((i >> (2 * k)) & 1) << k) | (((i >> (2 * k + 1)) & 1) << (k + 4));
+        t.r[i] = (packed[m] & 0x0fffffffffffffffull) | ((u64)count[m] << 60);
+    }
+    return t;
+}
+__device__ const TriRows g_tri_rows = make_interleaved_rows();
+
 struct Dims {
     int64_t rx, ry, rz;   // rx = ALL planes of the call (a batch of B grids is a stack of B * xper planes)
     int64_t P;  // units per x plane = ry * ncz
@@ -1222,6 +1241,9 @@ __device__ inline u32 rank32(u32 crossing, u32 lowm, u32 base) {   // base + cro
     return (u32)__builtin_popcount(crossing & lowm) + base;
 }
 
+#ifndef P3D_TAB_GLOBAL
+#define P3D_TAB_GLOBAL 1
+#endif
 template <int N>
 __device__ inline u32 row_nibble(u32 lo, u32 hi) {   // nibble N of the 64-bit table row (lo, hi)
     if constexpr (N < 8) return (lo >> (4 * N)) & 15u;
@@ -1237,7 +1259,9 @@ __global__ void __launch_bounds__(kBlock) k_faces2(const u64* __restrict__ bits,
         return;
     }
     constexpr int NS = (kBlock + NHALO + 1) > 2 * (kBlock + 1) ? (kBlock + NHALO + 1) : (NHALO >= kBlock ? 2 * (kBlock + 1) : kBlock + NHALO + 1);
+#if !P3D_TAB_GLOBAL
     __shared__ u64 s_tab[256];                           // case table row | triangle count << 60
+#endif
     __shared__ u64 s_w[2][NS + 1];                       // sign words of planes x and x+1 (read as a dword stream; one pad)
     __shared__ u32 s_e[2][3 * NS + 3];                   // per staged unit: {first id, offsets of the low half, of the high half}
     __shared__ unsigned short s_cells[4][kWaveCells];    // per wave: active cells of the round, unit-in-tile << 6 | z
@@ -1245,12 +1269,9 @@ __global__ void __launch_bounds__(kBlock) k_faces2(const u64* __restrict__ bits,
     __shared__ u32 s_tmp[4];
     const bool XLATE = a.xlate == 1 || (a.xlate == 2 && hdr[H_RECFORM] != 0ull);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    {   // (tables indexed by the INTERLEAVED corner mask: bit 2k = column k at z, bit 2k+1 = column k at z+1)
-        int m = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) m |= (((tid >> (2 * k)) & 1) << k) | (((tid >> (2 * k + 1)) & 1) << (k + 4));
-        s_tab[tid] = (g_tri_packed[m] & 0x0fffffffffffffffull) | ((u64)g_tri_count[m] << 60);
-    }
+#if !P3D_TAB_GLOBAL
+    s_tab[tid] = g_tri_rows.r[tid];
+#endif
     u32 pref = 0;
     if (XLATE) {
         if (a.xlate == 1) {
@@ -1433,7 +1454,11 @@ __global__ void __launch_bounds__(kBlock) k_faces2(const u64* __restrict__ bits,
             const u32 t0 = __builtin_amdgcn_alignbit(c0, a0, zz), t1 = __builtin_amdgcn_alignbit(c1, a1, zz);
             const u32 t2 = __builtin_amdgcn_alignbit(c2, a2, zz), t3 = __builtin_amdgcn_alignbit(c3, a3, zz);
             const u32 mask = (t0 & 3u) | ((t1 & 3u) << 2) | ((t2 & 3u) << 4) | ((t3 & 3u) << 6);
+#if P3D_TAB_GLOBAL
+            const u64 row = g_tri_rows.r[mask];   // (2 KiB, hot in the vector L1: keeps the block's LDS at six blocks per CU)
+#else
             const u64 row = s_tab[mask];
+#endif
             const u32 row_lo = (u32)row, row_hi = (u32)(row >> 32);
             const u32 nt = on ? row_hi >> 28 : 0u;
             // crossing words of this half (axis 0: columns (x,y) and (x,y+1); axis 1: (x,y) and (x+1,y); axis 2: all four)

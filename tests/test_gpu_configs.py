@@ -172,24 +172,29 @@ def test_chunk_prefix_handoff_under_load(gpu, built, tuning_env, kind):
     from primitive3d_amd.fields import perlin_grid
     if kind == "stack":   # 20 items x 68 chunks = 1360 chunks
         grids = torch.stack([perlin_grid((130, 256, 256), period=32, seed=s, device=gpu).half() for s in range(20)])
-        run = lambda: built.marching_cubes_batched(grids, 0.0)[:2]
         expect = [sum(x) for x in zip(*[torch_counts(grids[b], 0.0) for b in range(20)])]
+
+        def run():   # (face ids are local to an item: one soup per item, concatenated)
+            v, f, vo, fo = built.marching_cubes_batched(grids, 0.0)
+            vo, fo = vo.tolist(), fo.tolist()
+            return v.shape[0], f.shape[0], torch.cat([soup_hashes(v[vo[b]:vo[b + 1]], f[fo[b]:fo[b + 1]]) for b in range(20)])
     else:                 # 65 x 16 = 1040 chunks
         g = perlin_grid((520, 512, 512), period=48, seed=5, device=gpu).half()
         from primitive3d_amd import capi
-        run = lambda: capi.extract_fused(g, 0.0, cap_vertices=1 << 24, cap_faces=1 << 25)
         expect = list(torch_counts(g, 0.0))
+
+        def run():
+            v, f = capi.extract_fused(g, 0.0, cap_vertices=1 << 24, cap_faces=1 << 25)
+            return v.shape[0], f.shape[0], soup_hashes(v, f)
     tuning_env("P3D_NO_CHUNK_PRE", "1")
-    v0, f0 = run()
+    nv0, nf0, h0 = run()
     torch.cuda.synchronize()
-    assert [v0.shape[0], f0.shape[0]] == expect
-    key = lambda v, f: soup_hashes(v, f)
-    h0 = key(v0, f0)
+    assert [nv0, nf0] == expect
     tuning_env("P3D_NO_CHUNK_PRE", None)
     for _ in range(12):
-        v, f = run()
-        assert (v.shape[0], f.shape[0]) == (v0.shape[0], f0.shape[0])
-        assert torch.equal(key(v, f), h0)
+        nv, nf, h = run()
+        assert (nv, nf) == (nv0, nf0)
+        assert torch.equal(h, h0)
 
 
 def test_batch_whose_totals_exceed_int32_goes_item_by_item(gpu, built, tuning_env):
