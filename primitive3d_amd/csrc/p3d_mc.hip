@@ -498,6 +498,30 @@ __global__ void __launch_bounds__(kBlock) k_emit_vertices(const T* __restrict__ 
 // order is whatever its atomicAdd produced (marching_cubes.cu:200), so any order is in spec.
 // Corner bit weights and edge numbering follow marching_cubes.cu:49-57 and :178-192.
 // ---------------------------------------------------------------------------------------------
+// Division of a 32-bit number by a run-time constant as multiply-high + shifts (the magic number is made on the host:
+// a 32-bit hardware-less division costs ~25 vector instructions, and the face kernels do three per block).
+struct FastDiv {
+    u32 d, m, sh;   // d == 1: identity
+};
+inline FastDiv make_fastdiv(u32 d) {   // (libdivide's branch-free scheme: exact for every 32-bit n, d >= 1)
+    FastDiv f{d, 0u, 0u};
+    if (d <= 1u) return f;
+    u32 fl = 31u - (u32)__builtin_clz(d);
+    const u64 num = 1ull << (32 + fl);
+    u64 m = num / d;
+    const u64 rem = num % d;
+    m += m;
+    if (2 * rem >= d) m += 1;
+    f.m = (u32)(m + 1);
+    f.sh = fl;
+    return f;
+}
+__device__ inline u32 fd_div(u32 n, const FastDiv& f) {
+    if (f.d == 1u) return n;   // (uniform)
+    const u32 q = __umulhi(f.m, n);
+    return (((n - q) >> 1) + q) >> f.sh;
+}
+
 struct FaceArgs {
     int xlate;  // rec[].x may be region * 2^26 + slot (straight from the streaming kernel) and is made dense on the fly:
                 // 0 never; 1 yes, region bases from the call's cursors (the header is not finished yet);
@@ -517,6 +541,8 @@ struct FaceArgs {
     const u64* cursors;    // xlate: the call's 32 vertex-region cursors
     u64* mb;               // result mailbox slot (or null) and the call's sequence number (compaction block 0 reports)
     u64 seq;
+    FastDiv div_tpp, div_xper, div_ncz;   // (filled in by launch_faces)
+    int xw_shift;                         // log2(xw)
 };
 
 #ifndef P3D_WAVE_CELLS
@@ -1272,11 +1298,18 @@ __global__ void __launch_bounds__(kBlock) k_faces2(const u64* __restrict__ bits,
 #if !P3D_TAB_GLOBAL
     s_tab[tid] = g_tri_rows.r[tid];
 #endif
+    // (32-bit index arithmetic by multiply-high: three divisions by run-time constants)
+    const u32 b = (u32)blockIdx.x - (u32)cp.nblocks;
+    const u32 x32 = fd_div(b, a.div_tpp);
+    const int64_t x = x32;
+    const int64_t tile = b - x32 * (u32)a.tpp;
+    const u32 item = d.stack ? fd_div(x32, a.div_xper) : 0u;
+    const u32 xl = x32 - item * (u32)d.xper;
+    if (xl == (u32)d.xper - 1u) return;   // the last plane of an item has no cell layer above it (stack of items only)
     u32 pref = 0;
     if (XLATE) {
         if (a.xlate == 1) {
-            const u32 it = d.stack ? (((u32)blockIdx.x - (u32)cp.nblocks) / (u32)a.tpp) / (u32)d.xper : 0u;
-            const u32 cnt = lane < kRegions ? (u32)a.cursors[(size_t)it * kCursorBlockWords + lane * kCursorStride] : 0u;
+            const u32 cnt = lane < kRegions ? (u32)a.cursors[(size_t)item * kCursorBlockWords + lane * kCursorStride] : 0u;
             pref = wave_prefix_sum(cnt) - cnt;
         } else if (lane < kRegions) {
             pref = (u32)hdr[H_PREFIX + lane];
@@ -1292,16 +1325,9 @@ __global__ void __launch_bounds__(kBlock) k_faces2(const u64* __restrict__ bits,
         b0 = (u32)acc;
         bhalo = (u32)(acc + a.rank_counts[(size_t)a.rank * a.rank_stride]);
     }
-    const u32 b = (u32)blockIdx.x - (u32)cp.nblocks;
-    const u32 x32 = b / (u32)a.tpp;
-    const int64_t x = x32;
-    const int64_t tile = b - x32 * (u32)a.tpp;
-    const u32 item = d.stack ? x32 / (u32)d.xper : 0u;
-    const u32 xl = x32 - item * (u32)d.xper;
-    if (xl == (u32)d.xper - 1u) return;
     const u32 my_tris = a.tile_tris[b];
     const int64_t p = tile * kBlock + tid;
-    const int64_t y = (u32)p / (u32)d.ncz;
+    const int64_t y = fd_div((u32)p, a.div_ncz);   // (p < 2^31: check_dims)
     const int c = (int)(p - y * d.ncz);
     const bool valid = (p < d.P) && (y + 1 < d.ry);
     const bool more = c + 1 < d.ncz;
@@ -1317,11 +1343,14 @@ __global__ void __launch_bounds__(kBlock) k_faces2(const u64* __restrict__ bits,
     constexpr int NST = (NS + kBlock - 1) / kBlock;
     u64 st_w0[NST], st_w1[NST], st_y0[NST], st_y1[NST];
     uint2 st_r0[NST], st_r1[NST];
+    const int wave0 = wave * 64;   // (a wave skips a pass none of whose 64 entries exists: the pass behind the tile's 256
+                                   //  units stages at most NHALO + 1 entries -- one wave's worth for the short-row variant)
 #pragma unroll
     for (int q = 0; q < NST; ++q) {
         const int i = tid + q * kBlock;
         st_w0[q] = st_w1[q] = st_y0[q] = st_y1[q] = 0ull;
         st_r0[q] = st_r1[q] = make_uint2(0u, 0u);
+        if (wave0 + q * kBlock >= nstage) continue;   // wave-uniform
         const int64_t pi = (one_range || i <= kBlock) ? p0 + i : p0 + d.ncz + (i - kBlock - 1);
         if (i < nstage && pi < d.P) {
             const int64_t ui = x * d.P + pi;
@@ -1337,7 +1366,7 @@ __global__ void __launch_bounds__(kBlock) k_faces2(const u64* __restrict__ bits,
     }
     u32 cs = 0;
     {
-        const int64_t mychunk = (int64_t)(item * (u32)a.cpi + (xl / (u32)a.xw) * (u32)a.tpp) + tile;
+        const int64_t mychunk = (int64_t)(item * (u32)a.cpi + (xl >> a.xw_shift) * (u32)a.tpp) + tile;
         if (a.chunk_pre) {
             if (tid == 0) cs = a.chunk_pre[mychunk];
         } else {
@@ -1348,8 +1377,9 @@ __global__ void __launch_bounds__(kBlock) k_faces2(const u64* __restrict__ bits,
     u32* const E0 = s_e[0];
     u32* const E1 = s_e[1];
 #pragma unroll
-    for (int q = 0; q < NST; ++q) {   // (uniform trip count: the translation shuffles across lanes)
+    for (int q = 0; q < NST; ++q) {   // (wave-uniform trip count: the translation shuffles across the wave's lanes)
         const int i = tid + q * kBlock;
+        if (wave0 + q * kBlock >= nstage) continue;
         const u32 base0 = dense(st_r0[q].x) + b0;
         const u32 base1 = xhalo ? st_r1[q].x + bhalo : dense(st_r1[q].x) + b0;
         // offsets of the unit's first x / y / z edge id (bytes 0 / 1 / 2): low half = the record's, high half = plus
@@ -1496,8 +1526,24 @@ __global__ void __launch_bounds__(kBlock) k_faces2(const u64* __restrict__ bits,
             ids[11 * 64] = id11;
             // the batch's triangles, k-th triangle of every cell together: the lanes that have one write a DENSE run.
             // The three ids come back out of the lane's LDS column by table index.
+            // The ids of the first two triangles are read back before the first store (most cells have two; a cell with one
+            // reads three ids it does not use: row nibble 15 is clamped to a valid column).
+            typedef int i3u __attribute__((ext_vector_type(3), aligned(4)));
+            i3u tri0, tri1;
+            tri0.x = (int32_t)ids[row_nibble<0>(row_lo, row_hi) * 64];
+            tri0.y = (int32_t)ids[row_nibble<1>(row_lo, row_hi) * 64];
+            tri0.z = (int32_t)ids[row_nibble<2>(row_lo, row_hi) * 64];
+            tri1.x = (int32_t)ids[min(row_nibble<3>(row_lo, row_hi), 11u) * 64];
+            tri1.y = (int32_t)ids[min(row_nibble<4>(row_lo, row_hi), 11u) * 64];
+            tri1.z = (int32_t)ids[min(row_nibble<5>(row_lo, row_hi), 11u) * 64];
+            {   // k = 0: every listed cell has one
+                const u64 have = __ballot(on);
+                const u32 f = __builtin_amdgcn_mbcnt_hi((u32)(have >> 32), __builtin_amdgcn_mbcnt_lo((u32)have, rel));
+                if (on && f < cap_rel) __builtin_nontemporal_store(tri0, (i3u*)(wfaces + f * 3u));
+                rel += (u32)popc64(have);
+            }
             bool go = true;
-            static_for<0, 5>([&](auto kc) {
+            static_for<1, 5>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 if (!go) return;
                 const u64 have = __ballot((u32)k < nt);
@@ -1507,14 +1553,14 @@ __global__ void __launch_bounds__(kBlock) k_faces2(const u64* __restrict__ bits,
                 }
                 const u32 f = __builtin_amdgcn_mbcnt_hi((u32)(have >> 32), __builtin_amdgcn_mbcnt_lo((u32)have, rel));
                 if ((u32)k < nt && f < cap_rel) {
-                    // nibbles 3k, 3k+1, 3k+2 of the row
-                    const u32 e0 = row_nibble<3 * k>(row_lo, row_hi), e1 = row_nibble<3 * k + 1>(row_lo, row_hi);
-                    const u32 e2 = row_nibble<3 * k + 2>(row_lo, row_hi);
-                    typedef int i3u __attribute__((ext_vector_type(3), aligned(4)));
                     i3u tv;
-                    tv.x = (int32_t)ids[e0 * 64];
-                    tv.y = (int32_t)ids[e1 * 64];
-                    tv.z = (int32_t)ids[e2 * 64];
+                    if constexpr (k == 1) {
+                        tv = tri1;
+                    } else {
+                        tv.x = (int32_t)ids[row_nibble<3 * k>(row_lo, row_hi) * 64];
+                        tv.y = (int32_t)ids[row_nibble<3 * k + 1>(row_lo, row_hi) * 64];
+                        tv.z = (int32_t)ids[row_nibble<3 * k + 2>(row_lo, row_hi) * 64];
+                    }
                     __builtin_nontemporal_store(tv, (i3u*)(wfaces + f * 3u));
                 }
                 rel += (u32)popc64(have);
@@ -1771,17 +1817,23 @@ void launch_count_walk(dim3 grid, hipStream_t st, const u64* bits, const Dims& d
 }
 
 // the face launch: with `faces_here` one block per face tile, else the compaction blocks only
-void launch_faces(const Dims& d, const Ws& w, const u64* bits, const uint2* rec, const FaceArgs& a, const CompactArgs& cp,
+void launch_faces(const Dims& d, const Ws& w, const u64* bits, const uint2* rec, const FaceArgs& a_in, const CompactArgs& cp,
                   u64* hdr, int32_t* faces, int64_t capf, bool faces_here, hipStream_t st) {
     const dim3 fgrid((u32)((faces_here ? w.nb_f : 0) + cp.nblocks));
     if (fgrid.x == 0) return;
     if (tuning().faces_v >= 2) {
+        FaceArgs a = a_in;
+        a.div_tpp = make_fastdiv((u32)w.tpp);
+        a.div_xper = make_fastdiv((u32)d.xper);
+        a.div_ncz = make_fastdiv((u32)d.ncz);
+        a.xw_shift = __builtin_ctz((unsigned)w.xw);
         if (d.ncz <= 32)
             hipLaunchKernelGGL(k_faces2<32>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
         else
             hipLaunchKernelGGL(k_faces2<256>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
         return;
     }
+    const FaceArgs& a = a_in;
     if (d.ncz <= 32)
         hipLaunchKernelGGL(k_faces<32>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
     else
