@@ -51,7 +51,7 @@ def pybind_path() -> Path:
 
 def build_capi(force: bool = False, verbose: bool = False) -> Path:
     out = capi_path()
-    deps = [CSRC / "p3d_mc.hip", *sorted(CSRC.glob("*.inc")), ROOT / "include" / "p3d_mc.h"]
+    deps = [CSRC / "p3d_mc.hip", *sorted(CSRC.glob("*.inc")), *sorted(CSRC.glob("*.h")), ROOT / "include" / "p3d_mc.h"]
     if force or _stale(out, deps):
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
                # the reference epilogue is mul-then-add, never an FMA (marching_cubes.cu:298)

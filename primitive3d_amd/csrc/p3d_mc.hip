@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "../../include/p3d_mc.h"
+#include "fastdiv.h"
 #include "tri_table_packed.inc"
 
 namespace {
@@ -498,30 +499,6 @@ __global__ void __launch_bounds__(kBlock) k_emit_vertices(const T* __restrict__ 
 // order is whatever its atomicAdd produced (marching_cubes.cu:200), so any order is in spec.
 // Corner bit weights and edge numbering follow marching_cubes.cu:49-57 and :178-192.
 // ---------------------------------------------------------------------------------------------
-// Division of a 32-bit number by a run-time constant as multiply-high + shifts (the magic number is made on the host:
-// a 32-bit hardware-less division costs ~25 vector instructions, and the face kernels do three per block).
-struct FastDiv {
-    u32 d, m, sh;   // d == 1: identity
-};
-inline FastDiv make_fastdiv(u32 d) {   // (libdivide's branch-free scheme: exact for every 32-bit n, d >= 1)
-    FastDiv f{d, 0u, 0u};
-    if (d <= 1u) return f;
-    u32 fl = 31u - (u32)__builtin_clz(d);
-    const u64 num = 1ull << (32 + fl);
-    u64 m = num / d;
-    const u64 rem = num % d;
-    m += m;
-    if (2 * rem >= d) m += 1;
-    f.m = (u32)(m + 1);
-    f.sh = fl;
-    return f;
-}
-__device__ inline u32 fd_div(u32 n, const FastDiv& f) {
-    if (f.d == 1u) return n;   // (uniform)
-    const u32 q = __umulhi(f.m, n);
-    return (((n - q) >> 1) + q) >> f.sh;
-}
-
 struct FaceArgs {
     int xlate;  // rec[].x may be region * 2^26 + slot (straight from the streaming kernel) and is made dense on the fly:
                 // 0 never; 1 yes, region bases from the call's cursors (the header is not finished yet);

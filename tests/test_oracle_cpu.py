@@ -142,3 +142,42 @@ def test_openmp_oracle_is_identical_to_the_serial_one(threads):
         b = oracle_extract(g, thresh, lower, upper, threads=threads)
         for x, y in zip(a, b):
             assert np.array_equal(x, y, equal_nan=True), name
+
+
+def test_fastdiv_is_exact(tmp_path):
+    """primitive3d_amd/csrc/fastdiv.h (the face kernel's divisions by run-time constants as multiply-high + shifts, magic
+    numbers made on the host) against the hardware division: every d < 3000 with every n < 70000 plus random and extreme n,
+    and two million random (n, d) pairs -- compiled here with the host compiler."""
+    import subprocess
+    root = Path(__file__).resolve().parents[1]
+    src = tmp_path / "fd.cpp"
+    src.write_text('''
+#include <cstdio>
+#include <cstdlib>
+#include "fastdiv.h"
+int main() {
+    unsigned long long bad = 0;
+    srand(1);
+    for (uint32_t d = 1; d < 3000; ++d) {
+        const FastDiv f = make_fastdiv(d);
+        for (uint32_t n = 0; n < 70000; ++n) bad += fd_div(n, f) != n / d;
+        for (int k = 0; k < 500; ++k) { uint32_t n = ((uint32_t)rand() << 16) ^ (uint32_t)rand(); bad += fd_div(n, f) != n / d; }
+        const uint32_t edge[] = {0xffffffffu, 0x7fffffffu, 0x80000000u, d * 7u - 1u, d * 1000003u};
+        for (uint32_t n : edge) bad += fd_div(n, f) != n / d;
+    }
+    for (int k = 0; k < 2000000; ++k) {
+        uint32_t d = (((uint32_t)rand() << 16) ^ (uint32_t)rand()) | 1u;
+        if (k & 1) d >>= (rand() % 31);
+        if (!d) d = 1;
+        const FastDiv f = make_fastdiv(d);
+        const uint32_t n = ((uint32_t)rand() << 16) ^ (uint32_t)rand();
+        bad += fd_div(n, f) != n / d;
+    }
+    printf("%llu\\n", bad);
+    return bad != 0;
+}
+''')
+    exe = tmp_path / "fd"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", str(root / "primitive3d_amd" / "csrc"), str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "0", out.stdout + out.stderr
