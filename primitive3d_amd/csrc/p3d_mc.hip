@@ -46,10 +46,8 @@ typedef unsigned int u32;
 
 #include "tri_count_bitsliced.inc"
 
-__device__ const u64 g_tri_packed[256] = {P3D_TRI_TABLE_PACKED};
-__device__ const unsigned char g_tri_count[256] = {P3D_TRI_COUNT};
-
-// The same table for k_faces2: indexed by the INTERLEAVED corner mask (bit 2k = column k at z, bit 2k+1 = column k at
+// The case table (marching_cubes.h:21-277, nibble-packed in tri_table_packed.inc) as k_faces reads it: indexed by the
+// INTERLEAVED corner mask (bit 2k = column k at z, bit 2k+1 = column k at
 // z+1 -- what one shift per column yields; the reference's mask, marching_cubes.cu:49-57, has bits 0-3 at z and 4-7 at
 // z+1: a fixed permutation of the index), with the row's triangle count in the top nibble (a row uses 15 nibbles).
 struct TriRows {
@@ -204,38 +202,6 @@ __device__ inline void write_lane2(int& lo, int& hi, u64 m) {
         : "s"((int)(u32)m), "s"((int)(u32)(m >> 32)), "n"(J)
         : "vcc");
 }
-// Four units at a time: the four compares first, then the eight v_writelane -- every v_writelane then reads an SGPR
-// pair written at least three VALU instructions earlier, so the hazard above needs no wait state at all (one
-// instruction slot per unit saved: the 32 s_nop of a plane cost as much issue time as 32 vector instructions).
-// sign word of unit J+q = (v_q > thresh) over the 64 lanes (ordered compare: NaN -> 0, marching_cubes.cu:25).
-#ifndef P3D_WL_GROUP
-#define P3D_WL_GROUP 1   // dev: 4 = grouped compares (no s_nop)
-#endif
-template <int J>
-__device__ inline void cmp_write_lane4(int& lo, int& hi, float v0, float v1, float v2, float v3, float thresh) {
-    u64 m0, m1, m2, m3;
-    asm("v_cmp_gt_f32_e64 %0, %4, %8\n\t"
-        "v_cmp_gt_f32_e64 %1, %5, %8\n\t"
-        "v_cmp_gt_f32_e64 %2, %6, %8\n\t"
-        "v_cmp_gt_f32_e64 %3, %7, %8"
-        : "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
-        : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(thresh));
-    // (the first v_writelane reads the pair written by the FIRST compare, three instructions back; the last compare's
-    //  pair is read six instructions later)
-    asm("v_writelane_b32 %0, %2, %10\n\t"
-        "v_writelane_b32 %1, %3, %10\n\t"
-        "v_writelane_b32 %0, %4, %11\n\t"
-        "v_writelane_b32 %1, %5, %11\n\t"
-        "v_writelane_b32 %0, %6, %12\n\t"
-        "v_writelane_b32 %1, %7, %12\n\t"
-        "v_writelane_b32 %0, %8, %13\n\t"
-        "v_writelane_b32 %1, %9, %13"
-        : "+v"(lo), "+v"(hi)
-        : "s"((int)(u32)m0), "s"((int)(u32)(m0 >> 32)), "s"((int)(u32)m1), "s"((int)(u32)(m1 >> 32)), "s"((int)(u32)m2),
-          "s"((int)(u32)(m2 >> 32)), "s"((int)(u32)m3), "s"((int)(u32)(m3 >> 32)), "n"(J), "n"(J + 1), "n"(J + 2),
-          "n"(J + 3));
-}
-
 __device__ inline float load_f32(const float* p) { return *p; }
 __device__ inline float load_f32(const __half* p) { return __half2float(*p); }
 
@@ -518,8 +484,8 @@ struct FaceArgs {
     const u64* cursors;    // xlate: the call's 32 vertex-region cursors
     u64* mb;               // result mailbox slot (or null) and the call's sequence number (compaction block 0 reports)
     u64 seq;
-    FastDiv div_tpp, div_xper, div_ncz;   // (filled in by launch_faces)
-    int xw_shift;                         // log2(xw)
+    FastDiv div_tpp = {1, 0, 0}, div_xper = {1, 0, 0}, div_ncz = {1, 0, 0};   // (filled in by launch_faces)
+    int xw_shift = 0;                                                           // log2(xw)
 };
 
 #ifndef P3D_WAVE_CELLS
@@ -925,317 +891,35 @@ __global__ void __launch_bounds__(kBlock) k_export_plane_records(const uint2* __
     out[i] = r;
 }
 
-// Faces from sign words + vertex-id records.  One block = one tile; after ONE block barrier (the staging below) its
-// four waves never meet again: wave w owns the cells of units 64w .. 64w+63 and knows where its faces start
-// (wave_off from k_face_count_walk + the chunk totals before its chunk).
-//   phase A (lane = unit, block) : the 2x2 column words, their next-chunk bits, vertex-id records -> LDS
-//   phase B (lane = unit, wave)  : dense list of the wave's active cells (2 .. 16 rounds over z slices if it does not fit)
-//   phase C (lane = cell, wave)  : corner mask, the cell's 12 edge vertex ids -> the lane's column of the wave's LDS
-//                                  slice, then the k-th triangles of all cells together (k < 5): three ids read back
-//                                  by table index, one 12-byte streaming store per lane, the lanes that have a k-th
-//                                  triangle writing a dense run (a lane-per-triangle second phase cost more
-//                                  instructions than it saved)
-// No block barrier and no global load sits between a face store and the next batch (a barrier's or a load's
-// s_waitcnt vmcnt would wait for the stores in flight too).  With a.xlate the records are read in the streaming
-// kernel's region form (region * 2^26 + slot) and made dense on the fly from the 32 region cursors, so no pass over
-// the records has to precede the faces.
-// NHALO: units staged beyond the tile's 256 for the y+1 columns -- 32 (rows of at most 32 chunks, rz <= 2048: 26.7 KiB
-// of LDS, six tiles per CU) or 256 (any row length: fewer tiles per CU).
-template <int NHALO>
-__global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, const uint2* __restrict__ rec, Dims d,
-                                                  FaceArgs a, CompactArgs cp, u64* __restrict__ hdr,
-                                                  int32_t* __restrict__ faces, int64_t cap_faces) {
-    if ((int)blockIdx.x < cp.nblocks) {  // the launch's first blocks move the vertices (uniform per block)
-        compact_block(cp, hdr, a.mb, a.seq);
-        return;
-    }
-    // staged units per plane: the tile, its y+1 halo and one more unit (z+1 of the last); rows longer than NHALO
-    // chunks use two separate ranges of 257
-    constexpr int NS = (kBlock + NHALO + 1) > 2 * (kBlock + 1) ? (kBlock + NHALO + 1) : (NHALO >= kBlock ? 2 * (kBlock + 1) : kBlock + NHALO + 1);
-    __shared__ u64 s_tab[256];
-    __shared__ unsigned char s_ntri[256];
-    __shared__ u64 s_w[2][NS];                           // sign words of planes x and x+1 (bit k = sign at z = 64c+k)
-    __shared__ uint2 s_r[2][NS];                         // their vertex-id records
-    __shared__ unsigned char s_nb[kBlock];               // per unit: bit j = sign of column j at the first voxel of the next chunk
-    __shared__ unsigned short s_cells[4][kWaveCells];    // per wave: active cells of the round, unit-in-tile << 6 | z
-    __shared__ u32 s_ids[4][12][64];                     // per wave: vertex ids of the batch's cells' 12 edges
-    __shared__ u32 s_tmp[4];
-    const bool XLATE = a.xlate == 1 || (a.xlate == 2 && hdr[H_RECFORM] != 0ull);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // the case tables are indexed by the INTERLEAVED corner mask (bit 2k = column k at z, bit 2k+1 = column k at z+1:
-    // what one shift per column yields); the reference's mask (marching_cubes.cu:49-57: bits 0-3 at z, 4-7 at z+1) is
-    // this fixed permutation of it
-    {
-        int m = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) m |= (((tid >> (2 * k)) & 1) << k) | (((tid >> (2 * k + 1)) & 1) << (k + 4));
-        s_tab[tid] = g_tri_packed[m];
-        s_ntri[tid] = g_tri_count[m];
-    }
-    // dense base of every vertex region = exclusive prefix over the region cursors, kept by EVERY wave in a register
-    // (lane r = base of region r): the records are translated once, when they are staged, not once per cell
-    u32 pref = 0;
-    if (XLATE) {
-        if (a.xlate == 1) {
-            // (a stack of items: the cursor block of this tile's item; vertex ids are local to the item)
-            const u32 it = d.stack ? (((u32)blockIdx.x - (u32)cp.nblocks) / (u32)a.tpp) / (u32)d.xper : 0u;
-            const u32 cnt = lane < kRegions ? (u32)a.cursors[(size_t)it * kCursorBlockWords + lane * kCursorStride] : 0u;
-            pref = wave_prefix_sum(cnt) - cnt;
-        } else if (lane < kRegions) {
-            pref = (u32)hdr[H_PREFIX + lane];
-        }
-    }
-    auto dense = [&](u32 v) -> u32 {
-        return XLATE ? (v & 0x3ffffffu) + (u32)__builtin_amdgcn_ds_bpermute((int)(((v >> 26) & (kRegions - 1)) << 2), (int)pref) : v;
-    };
-    // id bases (a slab of a multi-GPU volume numbers its vertices after the ranks before it)
-    u32 b0 = (u32)a.vid_base, bhalo = (u32)a.halo_vid_base;
-    if (a.rank_counts) {  // uniform: a handful of scalar loads
-        int64_t acc = 0;
-        for (int r = 0; r < a.rank; ++r) acc += a.rank_counts[(size_t)r * a.rank_stride];
-        b0 = (u32)acc;
-        bhalo = (u32)(acc + a.rank_counts[(size_t)a.rank * a.rank_stride]);
-    }
-
-    // (32-bit index arithmetic: a 64-bit division costs more than a hundred instructions per wave)
-    const u32 b = (u32)blockIdx.x - (u32)cp.nblocks;
-    const u32 x32 = b / (u32)a.tpp;
-    const int64_t x = x32;
-    const int64_t tile = b - x32 * (u32)a.tpp;
-    const u32 item = d.stack ? x32 / (u32)d.xper : 0u;
-    const u32 xl = x32 - item * (u32)d.xper;
-    if (xl == (u32)d.xper - 1u) return;   // the last plane of an item has no cell layer above it (stack of items only)
-    const u32 my_tris = a.tile_tris[b];
-    const int64_t p = tile * kBlock + tid;
-    const int64_t y = (u32)p / (u32)d.ncz;   // (p < 2^31: check_dims)
-    const int c = (int)(p - y * d.ncz);
-    const bool valid = (p < d.P) && (y + 1 < d.ry);  // x+1 < rx by grid construction
-    const bool more = c + 1 < d.ncz;
-
-    // phase A: the units [tile start, +256) of planes x and x+1, the same ranges one row up (y+1: "+ncz" units, or a
-    // second range of 256 when a row is longer than NHALO chunks), and one unit more (the z+1 neighbour of the last).
-    // A cell's four columns W00,W10,W11,W01 are then plane 0/1 at index t and t + hoff.
-    // ALL global loads of the prologue are issued before any of them is waited for -- the tile's triangle count, the
-    // region cursors (above), the staged words and records, this thread's share of the chunk totals: one memory round
-    // trip instead of three dependent ones (-5 us at 512^3).
-    const bool one_range = d.ncz <= NHALO;
-    const int hoff = one_range ? d.ncz : kBlock + 1;   // index distance of the y+1 column
-    const int nstage = one_range ? kBlock + d.ncz + 1 : 2 * (kBlock + 1);
-    const int64_t p0 = tile * kBlock;
-    const bool xhalo = a.halo_last && (x + 1 == d.rx - 1);  // columns 1,2 live in the imported plane
-    constexpr int NST = (NS + kBlock - 1) / kBlock;   // staged entries per thread
-    u64 st_w0[NST], st_w1[NST];
-    uint2 st_r0[NST], st_r1[NST];
-#pragma unroll
-    for (int q = 0; q < NST; ++q) {
-        const int i = tid + q * kBlock;
-        st_w0[q] = st_w1[q] = 0ull;
-        st_r0[q] = st_r1[q] = make_uint2(0u, 0u);
-        const int64_t pi = (one_range || i <= kBlock) ? p0 + i : p0 + d.ncz + (i - kBlock - 1);
-        if (i < nstage && pi < d.P) {
-            const int64_t ui = x * d.P + pi;
-            st_w0[q] = bits[ui];
-            st_w1[q] = bits[ui + d.P];
-            st_r0[q] = rec[ui];  // only entries of units that own vertices are meaningful
-            st_r1[q] = rec[ui + d.P];
-        }
-    }
-    // faces of the chunks before this tile's chunk (summed by the whole block, or looked up)
-    u32 cs = 0;
-    {
-        const int64_t mychunk = (int64_t)(item * (u32)a.cpi + (xl / (u32)a.xw) * (u32)a.tpp) + tile;
-        if (a.chunk_pre) {
-            if (tid == 0) cs = a.chunk_pre[mychunk];
-        } else {
-            for (int64_t i = tid; i < mychunk; i += kBlock) cs += a.chunk_sum[i];
-        }
-    }
-    if (my_tris == 0u) return;  // nothing to emit here (block-uniform; most tiles of a sparse field)
-#pragma unroll
-    for (int q = 0; q < NST; ++q) {   // (uniform trip count: the translation shuffles across lanes)
-        const int i = tid + q * kBlock;
-        // first vertex id of the unit, final form: region form made dense, id base added (records of an imported halo
-        // plane arrive dense, in the neighbour's numbering)
-        st_r0[q].x = dense(st_r0[q].x) + b0;
-        st_r1[q].x = xhalo ? st_r1[q].x + bhalo : dense(st_r1[q].x) + b0;
-        if (i < nstage) {
-            s_w[0][i] = st_w0[q];
-            s_w[1][i] = st_w1[q];
-            s_r[0][i] = st_r0[q];
-            s_r[1][i] = st_r1[q];
-        }
-    }
-    {
-        cs = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum(cs), 63);
-        if (lane == 0) s_tmp[wave] = cs;
-    }
-    __syncthreads();  // the only block barrier: staging done (no store is in flight yet)
-#ifdef P3D_FACES_ABL   // dev-only: 1 = prologue only (wrong results)
-    if (P3D_FACES_ABL == 1) return;
-#endif
-    // first face of this wave (face indices fit 32 bits: F <= int32, p3d_mc_read_counts) and the capacity as u32
-    u32 wrun = (s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3]) + a.wave_off[b * 4 + wave];
-    const u32 cap32 = (u32)min(cap_faces, (int64_t)0x7fffffff);
-
-    // column k of unit t: (plane, index)
-    auto colw = [&](int k, int t) -> u64 { return s_w[(k == 1 || k == 2) ? 1 : 0][t + (k >= 2 ? hoff : 0)]; };
-    auto colr = [&](int k, int t) -> uint2 { return s_r[(k == 1 || k == 2) ? 1 : 0][t + (k >= 2 ? hoff : 0)]; };
-    // per unit (lane = unit of this wave): next-chunk bits, active cells
-    u64 act_all = 0;
-    {
-        int nbits = 0;
-        u64 orr = 0, andd = ~0ull;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const u64 Wk = valid ? colw(k, tid) : 0ull;
-            const u64 nb = (valid && more) ? (colw(k, tid + 1) & 1ull) : 0ull;
-            const u64 S = (Wk >> 1) | (nb << 63);
-            nbits |= (int)nb << (2 * k + 1);
-            orr |= Wk | S;
-            andd &= Wk & S;
-        }
-        s_nb[tid] = (unsigned char)nbits;
-        if (valid) act_all = orr & ~andd & zedge(d, c);
-    }
-    wave_lds_sync();  // s_nb of this wave's units is read by this wave's cell lanes
-
-    // interleaved corner mask of a cell: one 64-bit shift per column yields its bits at z and z+1; the z+1 corners of a
-    // chunk's last voxel live in the next chunk (s_nb, stored in the same interleaved positions)
-    auto cell_mask = [&](int t, int z) {
-        const u32 t0 = (u32)(colw(0, t) >> z), t1 = (u32)(colw(1, t) >> z);
-        const u32 t2 = (u32)(colw(2, t) >> z), t3 = (u32)(colw(3, t) >> z);
-        const u32 m = (t0 & 3u) | ((t1 & 3u) << 2) | ((t2 & 3u) << 4) | ((t3 & 3u) << 6);
-        return (int)(m | (z == 63 ? (u32)s_nb[t] : 0u));
-    };
-
-    // the wave's cells are expanded into LDS in one round when they fit, else in 2, 4, 8 or 16 rounds over z slices: the
-    // widest slice width (64, 32, ... voxels) whose fullest slice fits the window; 4-voxel slices always fit (64 units x 4)
-    static_assert(kWaveCells >= 256, "a 4-voxel z slice of a wave holds up to 256 cells");
-    int wbits = 64;
-    {
-        u32 fullest = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum((u32)popc64(act_all)), 63);
-        while (fullest > (u32)kWaveCells && wbits > 4) {   // (wave-uniform)
-            wbits >>= 1;
-            fullest = 0;
-            for (int sl = 0; sl < 64; sl += wbits) {
-                const u64 m = ((1ull << wbits) - 1ull) << sl;
-                fullest = max(fullest, (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum((u32)popc64(act_all & m)), 63));
-            }
-        }
-    }
-    const int rounds = 64 / wbits;
-    unsigned short* const cells = s_cells[wave];
-
-    for (int rd = 0; rd < rounds; ++rd) {
-        u64 act = rounds == 1 ? act_all : (act_all & (((1ull << wbits) - 1ull) << (wbits * rd)));
-        // phase B
-        const u32 pc = (u32)popc64(act);
-        const u32 inc0 = wave_prefix_sum(pc);
-        const u32 na = (u32)__builtin_amdgcn_readlane((int)inc0, 63);
-        u32 off = inc0 - pc;
-        while (act) {
-            const int z = __ffsll((long long)act) - 1;
-            act &= act - 1;
-            cells[off++] = (unsigned short)((tid << 6) | z);
-        }
-        wave_lds_sync();
-
-        for (u32 i0 = 0; i0 < na; i0 += 64) {
-            // phase C (lane = cell)
-            const u32 i = i0 + lane;
-            int mask = 0;
-            u32 nt = 0;
-            if (i < na) {
-                const int cell = cells[i];
-                const int t = cell >> 6, z = cell & 63;
-                mask = cell_mask(t, z);
-                nt = s_ntri[mask];
-                if (nt) {
-                    // crossing words of the 4 columns within this chunk
-                    const u64 W0 = colw(0, t), W1 = colw(1, t), W2 = colw(2, t), W3 = colw(3, t);
-                    const u64 lowm = below(z);
-                    const u64 Cx0 = W0 ^ W1, Cx3 = W3 ^ W2;   // axis-0 edges of columns (x,y) and (x,y+1)
-                    const u64 Cy0 = W0 ^ W3, Cy1 = W1 ^ W2;   // axis-1 edges of columns (x,y) and (x+1,y)
-                    const uint2 r0 = colr(0, t), r1 = colr(1, t), r2 = colr(2, t), r3 = colr(3, t);
-                    const u32 v0 = r0.x, v1 = r1.x, v2 = r2.x, v3 = r3.x;   // (made final when they were staged)
-                    u32 id[12];
-                    // edges at z (ranks among the bits below z)
-                    id[0] = v0 + (u32)popc64(Cx0 & lowm);
-                    id[2] = v3 + (u32)popc64(Cx3 & lowm);
-                    id[3] = v0 + (r0.y & 0xffffu) + (u32)popc64(Cy0 & lowm);
-                    id[1] = v1 + (r1.y & 0xffffu) + (u32)popc64(Cy1 & lowm);
-                    // edges at z+1: one more if the edge at z exists; the first voxel of the next chunk has rank 0
-                    if (z < 63) {
-                        id[4] = id[0] + (u32)((Cx0 >> z) & 1ull);
-                        id[6] = id[2] + (u32)((Cx3 >> z) & 1ull);
-                        id[7] = id[3] + (u32)((Cy0 >> z) & 1ull);
-                        id[5] = id[1] + (u32)((Cy1 >> z) & 1ull);
-                    } else {
-                        // next chunk of the same row (c+1 < ncz is implied by a valid z+1): the next staged unit
-                        const uint2 n0 = colr(0, t + 1), n1 = colr(1, t + 1), n3 = colr(3, t + 1);
-                        id[4] = n0.x;
-                        id[6] = n3.x;
-                        id[7] = n0.x + (n0.y & 0xffffu);
-                        id[5] = n1.x + (n1.y & 0xffffu);
-                    }
-                    // axis-2 edges of the 4 columns (always inside this chunk): crossing word = W ^ (W >> 1); the bit the
-                    // next chunk would shift in lands at position 63, which below(z) never includes
-                    id[8] = v0 + (r0.y >> 16) + (u32)popc64((W0 ^ (W0 >> 1)) & lowm);
-                    id[9] = v1 + (r1.y >> 16) + (u32)popc64((W1 ^ (W1 >> 1)) & lowm);
-                    id[10] = v2 + (r2.y >> 16) + (u32)popc64((W2 ^ (W2 >> 1)) & lowm);
-                    id[11] = v3 + (r3.y >> 16) + (u32)popc64((W3 ^ (W3 >> 1)) & lowm);
-#pragma unroll
-                    for (int e = 0; e < 12; ++e) s_ids[wave][e][lane] = id[e];
-                }
-            }
-            // the batch's triangles, k-th triangle of every cell together: the lanes that have one write a DENSE run
-            // (rank among them = position), so every store instruction covers contiguous bytes.  The three vertex ids
-            // come back out of the lane's LDS column by table index (a register array cannot be indexed per lane).
-            {
-                const u64 row = s_tab[mask];
-                for (u32 k = 0; k < 5; ++k) {
-                    const u64 have = __ballot(k < nt);
-                    if (!have) break;  // wave-uniform
-                    const u32 f = wrun + mbcnt64(have);
-                    if (k < nt && f < cap32) {
-                        const u32 row3 = (u32)(row >> (12 * k));
-                        int32_t* o3 = faces + (size_t)f * 3;
-                        // one 12-byte streaming store: the faces are never read again by this call, and keeping them
-                        // out of the caches lets the next call's streaming kernel start clean (-8 us on k_fused in a
-                        // back-to-back call stream; with the dense runs the stores fill whole sectors)
-                        typedef int i3u __attribute__((ext_vector_type(3), aligned(4)));
-                        i3u tv;
-                        tv.x = (int32_t)s_ids[wave][row3 & 15u][lane];
-                        tv.y = (int32_t)s_ids[wave][(row3 >> 4) & 15u][lane];
-                        tv.z = (int32_t)s_ids[wave][(row3 >> 8) & 15u][lane];
-                        __builtin_nontemporal_store(tv, (i3u*)o3);
-                    }
-                    wrun += (u32)popc64(have);
-                }
-            }
-            wave_lds_sync();
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// k_faces2 -- the face kernel, second version (round 3).  Same tiles, same face order, same prologue as k_faces; what
-// changed is the work per CELL, which is what bounds this kernel (VALU issue, not memory):
-//   * everything per cell is 32-bit.  The sign words are staged as a DWORD stream and a cell reads, per column, the
-//     two dwords starting at the half unit that holds z (index 2t + z/32): bit z and bit z+1 are always inside that
-//     window, also at z = 31 and at z = 63 (the next dword is the next half / the next chunk of the same row) -- no
-//     64-bit shifts, no "first bit of the next chunk" side table, no divergent branch for z = 63;
-//   * the vertex-id records are expanded ONCE PER STAGED UNIT into per-HALF form: {first id of the unit, byte offsets
-//     of the first x / y / z edge id of the low half, the same for the high half} -- the high half's offsets include
-//     the popcounts of the low halves of the unit's crossing words (computed by the staging thread from words it
-//     loads in the same round trip).  An id is then  popcount(crossing32 & below(z % 32)) + base + offset: and, bcnt,
-//     byte-add;
-//   * the ids of the four edges at z + 1 are the ids at z plus "edge at z crosses" (bits of the corner mask), or the
-//     next unit's first ids when z = 63;
-//   * every cell of the list is active, so the ids are computed unconditionally and all LDS reads of a batch are issued
-//     before the first wait (the old kernel had five dependent LDS round trips per batch in front of the triangles);
-//   * the case table row carries its triangle count in the top nibble (one lookup), the triangle rounds are unrolled
-//     with constant shifts and store through a wave-uniform base + 32-bit offset.
+// k_faces -- faces from sign words + vertex-id records (second version, round 3; the first is in the history up to
+// commit 6013781 and profiles/r03/ablation.txt compares them).  One block = one tile; after ONE block barrier (the
+// staging) its four waves never meet again: wave w owns the cells of units 64w .. 64w+63 and knows where its faces start
+// (wave_off from k_face_count_walk + the chunk totals before its chunk).
+//   phase A (lane = staged unit, block): sign words of planes x and x+1 -> LDS as a DWORD stream; the vertex-id records
+//            -> per-HALF-unit form {first id of the unit, byte offsets of the first x / y / z edge id of the low half, the
+//            same for the high half}: the high half's offsets include the popcounts of the low halves of the unit's
+//            crossing words (computed here, once per staged unit, from words loaded in the same round trip).  Region-form
+//            ids (region * 2^26 + slot, straight from the streaming kernel) are made dense on the fly from the 32 region
+//            cursors, so no pass over the records precedes the faces.
+//   phase B (lane = unit, wave)  : dense list of the wave's active cells (2 .. 16 rounds over z slices if it does not fit)
+//   phase C (lane = cell, wave)  : everything per cell is 32-bit.  Per column the cell reads the two dwords starting at
+//            the half unit that holds z (index 2t + z / 32): bit z and bit z+1 are always inside that window, also at
+//            z = 31 and z = 63 (the next dword is the next half / the next chunk of the same row) -- no 64-bit shifts, no
+//            side table for the first bit of the next chunk, no divergent branch.  An id is
+//            popcount(crossing32 & below(z % 32)) + base + offset (and, bcnt, byte-add); the four edges at z+1 are the
+//            ids at z plus "edge at z crosses" (bits of the corner mask), or the next unit's first ids when z = 63.  Every
+//            listed cell is active, so the ids are computed unconditionally and all LDS reads of a batch are issued
+//            before the first wait.  The 12 ids go to the lane's column of the wave's LDS slice and come back by table
+//            index (a register array cannot be indexed per lane); the k-th triangles of all cells are written together,
+//            the lanes that have one writing a dense run (one 12-byte streaming store per lane).  The case table row
+//            (global memory, 2 KiB, hot in the vector L1: keeps the block's LDS at six blocks per CU) carries its
+//            triangle count in the top nibble.
+// No block barrier and no dependent global load sits between a face store and the next batch.
+// NHALO: units staged beyond the tile's 256 for the y+1 columns -- 32 (rows of at most 32 chunks, rz <= 2048: 26.5 KiB of
+// LDS, six tiles per CU) or 256 (any row length: fewer tiles per CU).
+// Where the time goes (512^3 Perlin, profiles/r03/ablation.txt): prologue 20 us, cell lists 4, per-cell header + round
+// control + stores 27, id arithmetic 11, id read-back by table index 10.
 // ---------------------------------------------------------------------------------------------
 __device__ inline u32 add_byte0(u32 a, u32 packed) { return a + (packed & 0xffu); }
 __device__ inline u32 add_byte1(u32 a, u32 packed) { return a + ((packed >> 8) & 0xffu); }
@@ -1244,8 +928,8 @@ __device__ inline u32 rank32(u32 crossing, u32 lowm, u32 base) {   // base + cro
     return (u32)__builtin_popcount(crossing & lowm) + base;
 }
 
-#ifndef P3D_TAB_GLOBAL
-#define P3D_TAB_GLOBAL 1
+#ifndef P3D_FACES_ABL   // dev-only timing ablation (wrong results): 1 = return after the staging barrier
+#define P3D_FACES_ABL 0
 #endif
 template <int N>
 __device__ inline u32 row_nibble(u32 lo, u32 hi) {   // nibble N of the 64-bit table row (lo, hi)
@@ -1254,7 +938,7 @@ __device__ inline u32 row_nibble(u32 lo, u32 hi) {   // nibble N of the 64-bit t
 }
 
 template <int NHALO>
-__global__ void __launch_bounds__(kBlock) k_faces2(const u64* __restrict__ bits, const uint2* __restrict__ rec, Dims d,
+__global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, const uint2* __restrict__ rec, Dims d,
                                                    FaceArgs a, CompactArgs cp, u64* __restrict__ hdr,
                                                    int32_t* __restrict__ faces, int64_t cap_faces) {
     if ((int)blockIdx.x < cp.nblocks) {  // the launch's first blocks move the vertices (uniform per block)
@@ -1262,9 +946,6 @@ __global__ void __launch_bounds__(kBlock) k_faces2(const u64* __restrict__ bits,
         return;
     }
     constexpr int NS = (kBlock + NHALO + 1) > 2 * (kBlock + 1) ? (kBlock + NHALO + 1) : (NHALO >= kBlock ? 2 * (kBlock + 1) : kBlock + NHALO + 1);
-#if !P3D_TAB_GLOBAL
-    __shared__ u64 s_tab[256];                           // case table row | triangle count << 60
-#endif
     __shared__ u64 s_w[2][NS + 1];                       // sign words of planes x and x+1 (read as a dword stream; one pad)
     __shared__ u32 s_e[2][3 * NS + 3];                   // per staged unit: {first id, offsets of the low half, of the high half}
     __shared__ unsigned short s_cells[4][kWaveCells];    // per wave: active cells of the round, unit-in-tile << 6 | z
@@ -1272,9 +953,6 @@ __global__ void __launch_bounds__(kBlock) k_faces2(const u64* __restrict__ bits,
     __shared__ u32 s_tmp[4];
     const bool XLATE = a.xlate == 1 || (a.xlate == 2 && hdr[H_RECFORM] != 0ull);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#if !P3D_TAB_GLOBAL
-    s_tab[tid] = g_tri_rows.r[tid];
-#endif
     // (32-bit index arithmetic by multiply-high: three divisions by run-time constants)
     const u32 b = (u32)blockIdx.x - (u32)cp.nblocks;
     const u32 x32 = fd_div(b, a.div_tpp);
@@ -1386,6 +1064,9 @@ __global__ void __launch_bounds__(kBlock) k_faces2(const u64* __restrict__ bits,
         if (lane == 0) s_tmp[wave] = cs;
     }
     __syncthreads();  // the only block barrier: staging done (no store is in flight yet)
+#if P3D_FACES_ABL == 1
+    return;
+#endif
     // first face of this wave and the capacity, relative to it (a wave-tile emits at most 64 * 64 * 5 faces)
     const u32 wrun0 = (u32)__builtin_amdgcn_readfirstlane((int)((s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3]) + a.wave_off[b * 4 + wave]));
     const u32 cap32 = (u32)min(cap_faces, (int64_t)0x7fffffff);
@@ -1461,11 +1142,7 @@ __global__ void __launch_bounds__(kBlock) k_faces2(const u64* __restrict__ bits,
             const u32 t0 = __builtin_amdgcn_alignbit(c0, a0, zz), t1 = __builtin_amdgcn_alignbit(c1, a1, zz);
             const u32 t2 = __builtin_amdgcn_alignbit(c2, a2, zz), t3 = __builtin_amdgcn_alignbit(c3, a3, zz);
             const u32 mask = (t0 & 3u) | ((t1 & 3u) << 2) | ((t2 & 3u) << 4) | ((t3 & 3u) << 6);
-#if P3D_TAB_GLOBAL
-            const u64 row = g_tri_rows.r[mask];   // (2 KiB, hot in the vector L1: keeps the block's LDS at six blocks per CU)
-#else
-            const u64 row = s_tab[mask];
-#endif
+            const u64 row = g_tri_rows.r[mask];   // (2 KiB, hot in the vector L1)
             const u32 row_lo = (u32)row, row_hi = (u32)(row >> 32);
             const u32 nt = on ? row_hi >> 28 : 0u;
             // crossing words of this half (axis 0: columns (x,y) and (x,y+1); axis 1: (x,y) and (x+1,y); axis 2: all four)
@@ -1616,14 +1293,14 @@ int env_int(const char* name, int dflt) {
 // first call (no getenv in the per-call host path); -1 = "use the built-in rule".
 struct Tuning {
     int fused_blocks, fused_xt, fused_xt_tail, fused_tail_div, split_rows, small16, compact_blocks, compact_early,
-        test_id_limit, no_chunk_pre, test_index_limit, faces_v;
+        test_id_limit, no_chunk_pre, test_index_limit;
 };
 Tuning read_tuning() {
     return Tuning{env_int("P3D_FUSED_BLOCKS", 2048), env_int("P3D_FUSED_XT", -1), env_int("P3D_FUSED_XT_TAIL", -1),
                   env_int("P3D_FUSED_TAIL_DIV", 4), env_int("P3D_FUSED_SPLIT_ROWS", 1), env_int("P3D_FUSED_SMALL16", 1),
                   env_int("P3D_COMPACT_BLOCKS", 256), env_int("P3D_COMPACT_EARLY", 3),
                   env_int("P3D_TEST_ID_LIMIT", 1 << 26), env_int("P3D_NO_CHUNK_PRE", 0),
-                  env_int("P3D_TEST_INDEX_LIMIT", 0x7fffffff), env_int("P3D_FACES_V", 2)};
+                  env_int("P3D_TEST_INDEX_LIMIT", 0x7fffffff)};
 }
 Tuning g_tuning;
 std::once_flag g_tuning_once;
@@ -1798,19 +1475,11 @@ void launch_faces(const Dims& d, const Ws& w, const u64* bits, const uint2* rec,
                   u64* hdr, int32_t* faces, int64_t capf, bool faces_here, hipStream_t st) {
     const dim3 fgrid((u32)((faces_here ? w.nb_f : 0) + cp.nblocks));
     if (fgrid.x == 0) return;
-    if (tuning().faces_v >= 2) {
-        FaceArgs a = a_in;
-        a.div_tpp = make_fastdiv((u32)w.tpp);
-        a.div_xper = make_fastdiv((u32)d.xper);
-        a.div_ncz = make_fastdiv((u32)d.ncz);
-        a.xw_shift = __builtin_ctz((unsigned)w.xw);
-        if (d.ncz <= 32)
-            hipLaunchKernelGGL(k_faces2<32>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
-        else
-            hipLaunchKernelGGL(k_faces2<256>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
-        return;
-    }
-    const FaceArgs& a = a_in;
+    FaceArgs a = a_in;
+    a.div_tpp = make_fastdiv((u32)w.tpp);
+    a.div_xper = make_fastdiv((u32)d.xper);
+    a.div_ncz = make_fastdiv((u32)d.ncz);
+    a.xw_shift = __builtin_ctz((unsigned)w.xw);
     if (d.ncz <= 32)
         hipLaunchKernelGGL(k_faces<32>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
     else

@@ -1,25 +1,26 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): bench lines of every single-GPU config + rocprofv3 kernel stats + HBM traffic
 # counters + SQ counters of the headline config.   usage: tools/profile_round.sh <tag>   -> gpurun_out/<tag>/
-tag=${1:-r02}
+tag=${1:-r03}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
 cd $R
-python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err   # (carries other_configs: c2, c5, c4 on one GPU)
 python bench.py --config c2 --steps 50 --warmup 5 > $O/bench_c2.json 2> $O/bench_c2.err
 python bench.py --config c5 --steps 10 --warmup 3 > $O/bench_c5.json 2> $O/bench_c5.err
 python bench.py --config c4 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_c4_1gpu.json 2> $O/bench_c4.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $O/stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -- python3 $R/bench.py --config c5 --steps 10 --warmup 3 --no-cpu-baseline > $O/stats_c5.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -- python3 $R/bench.py --config c2 --steps 50 --warmup 5 --no-cpu-baseline > $O/stats_c2.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $O/pmc_write.log 2>&1
 # calibration of the counters on a kernel with a KNOWN byte count and the same access shape:
 # the staged extractor's k_classify reads the 512 MiB field once with dword loads and writes 16 MiB of sign words
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/cal_fetch -- python3 $R/tools/calibrate_fetch.py > $O/cal_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/cal_write -- python3 $R/tools/calibrate_fetch.py > $O/cal_write.log 2>&1
 cd $R && python3 tools/summarize_profile.py $O > $O/summary.txt 2>&1
 bash tools/pmc_round.sh $tag > /dev/null 2>&1
-cat $O/summary.txt $O/sq_summary.txt
+bash tools/pmc_round.sh $tag c5 > /dev/null 2>&1
+cat $O/summary.txt $O/sq_summary.txt $O/sq_summary_c5.txt
 # keep what travels back small: the raw traces are summarised above
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*counter_collection.csv" -size +1M -delete
