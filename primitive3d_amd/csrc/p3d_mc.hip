@@ -37,6 +37,7 @@
 
 #include "../../include/p3d_mc.h"
 #include "fastdiv.h"
+#include "half_round.h"
 #include "tri_table_packed.inc"
 
 namespace {
@@ -1566,23 +1567,6 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
     return P3D_OK;
 }
 
-
-// The largest fp16 value <= t (bit pattern; NaN for a NaN threshold).  For an fp16 sample v, `float(v) > t` is exactly
-// `v > half_round_down(t)`: no fp16 value lies between the two thresholds -- so the fp16 grid is classified with 16-bit
-// compares on the values as they come out of memory (marching_cubes.py:87 up-casts and compares in fp32).
-// Edge cases: t above the fp16 range -> 65504 (only +inf is inside); t below it -> -inf (everything but -inf and NaN
-// is inside); t in (-2^-24, 0) -> the negative subnormal next to zero (both zeros are inside).
-inline u32 half_round_down(float t) {
-    if (t != t) return 0x7e00u;
-    const _Float16 h = (_Float16)t;   // round to nearest
-    unsigned short b = __builtin_bit_cast(unsigned short, h);
-    if ((float)h > t) {   // rounded up: one step towards -inf
-        if ((b & 0x7fffu) == 0) b = 0x8001u;   // (+-0 -> the smallest negative subnormal)
-        else if (b & 0x8000u) b = (unsigned short)(b + 1);
-        else b = (unsigned short)(b - 1);
-    }
-    return b;
-}
 
 template <typename T, int NC, int RY>
 void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xform& t, int64_t x_origin, u64* bits,

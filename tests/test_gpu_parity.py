@@ -104,6 +104,28 @@ def test_fused_fp16(gpu):
     _assert_same_mesh(hip, oracle_extract(g.astype(np.float32), 0.0))
 
 
+FP16_THRESHOLDS = [0.1, -0.1, 1e-10, -1e-10, 5.9604645e-8, 6e-8, -6e-8, 0.0, -0.0, 65504.0, 65519.9, 65520.0, 70000.0,
+                   -65504.0, -65520.0, -70000.0, float("inf"), float("-inf"), float("nan"), 0.333251953125, 1.0009765625]
+
+
+@pytest.mark.parametrize("thresh", FP16_THRESHOLDS, ids=[repr(t) for t in FP16_THRESHOLDS])
+def test_fp16_grid_is_classified_like_its_upcast(gpu, thresh):
+    """fp16 grids are compared as 16-bit values against the threshold rounded DOWN to fp16 (p3d_mc.hip,
+    half_round_down): that must be exactly the reference's `grid.float() > thresh` (marching_cubes.py:87, cu:25) for every
+    threshold -- not representable in fp16, between the subnormals, beyond the fp16 range, infinite, NaN -- and every
+    sample value: +-0, subnormals, +-65504, +-inf, NaN.  The whole mesh against the oracle on the up-cast grid."""
+    rng = np.random.default_rng(11)
+    special = np.array([0.0, -0.0, 5.96e-8, -5.96e-8, 6.1e-5, -6.1e-5, 65504.0, -65504.0, np.inf, -np.inf, np.nan, 0.1, -0.1,
+                        0.333251953125, 0.33349609375, 1.0, 1.0009765625, 1e-7, -1e-7], dtype=np.float16)
+    g = rng.standard_normal((9, 11, 140)).astype(np.float16)
+    idx = rng.integers(0, g.size, size=g.size // 3)
+    g.reshape(-1)[idx] = special[rng.integers(0, len(special), size=len(idx))]
+    ref = oracle_extract(g.astype(np.float32), thresh)
+    with np.errstate(invalid="ignore"):
+        _assert_same_mesh(_hip_extract_fused(gpu, g, thresh, None, None, dtype=torch.float16), ref)
+        _assert_same_mesh(_hip_extract(gpu, g, thresh, None, None, dtype=torch.float16), ref)
+
+
 def test_fused_medium_perlin_192(gpu):
     from primitive3d_amd.fields import perlin_grid
     g = perlin_grid(192).numpy()

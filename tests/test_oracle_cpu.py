@@ -181,3 +181,48 @@ int main() {
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", str(root / "primitive3d_amd" / "csrc"), str(src), "-o", str(exe)])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip() == "0", out.stdout + out.stderr
+
+
+def test_half_round_down_is_exact(tmp_path):
+    """primitive3d_amd/csrc/half_round.h (the threshold of the 16-bit compares on fp16 grids): for every one of the 65536
+    fp16 bit patterns v and a few thousand thresholds t -- representable or not, subnormal, beyond the range, infinite,
+    NaN -- `v > half_round_down(t)` == `float(v) > t`.  Compiled with the ROCm clang (the host compiler of hipcc)."""
+    import shutil
+    import subprocess
+    clang = shutil.which("amdclang++") or "/opt/rocm/lib/llvm/bin/clang++"
+    if not Path(clang).exists():
+        pytest.skip("no clang with _Float16 on this machine")
+    root = Path(__file__).resolve().parents[1]
+    src = tmp_path / "hr.cpp"
+    src.write_text('''
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <limits>
+#include "half_round.h"
+int main() {
+    float ts[4000];
+    int n = 0;
+    const float fixed[] = {0.1f, -0.1f, 1e-10f, -1e-10f, 5.9604645e-8f, 6e-8f, -6e-8f, 0.0f, -0.0f, 65504.0f, 65519.9f, 65520.0f,
+                           70000.0f, -65504.0f, -65520.0f, -70000.0f, INFINITY, -INFINITY, NAN, 0.333251953125f,
+                           1.0009765625f, 6.1e-5f, -6.1e-5f, std::numeric_limits<float>::max(), -std::numeric_limits<float>::max()};
+    for (float f : fixed) ts[n++] = f;
+    srand(3);
+    const float scales[] = {1e-8f, 1e-5f, 1e-3f, 1.0f, 100.0f, 1e5f};
+    while (n < 4000) ts[n++] = ((float)rand() / RAND_MAX - 0.5f) * 2.0f * scales[rand() % 6];
+    unsigned long long bad = 0;
+    for (int i = 0; i < n; ++i) {
+        const _Float16 t16 = __builtin_bit_cast(_Float16, (unsigned short)half_round_down(ts[i]));
+        for (unsigned b = 0; b < 65536; ++b) {
+            const _Float16 v = __builtin_bit_cast(_Float16, (unsigned short)b);
+            bad += ((float)v > ts[i]) != (v > t16);
+        }
+    }
+    printf("%llu\\n", bad);
+    return bad != 0;
+}
+''')
+    exe = tmp_path / "hr"
+    subprocess.check_call([clang, "-O1", "-std=c++17", "-I", str(root / "primitive3d_amd" / "csrc"), str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "0", out.stdout + out.stderr
