@@ -1294,14 +1294,14 @@ int env_int(const char* name, int dflt) {
 // first call (no getenv in the per-call host path); -1 = "use the built-in rule".
 struct Tuning {
     int fused_blocks, fused_xt, fused_xt_tail, fused_tail_div, split_rows, small16, compact_blocks, compact_early,
-        test_id_limit, no_chunk_pre, test_index_limit;
+        test_id_limit, no_chunk_pre, test_index_limit, stack_nparts, stack_early;
 };
 Tuning read_tuning() {
     return Tuning{env_int("P3D_FUSED_BLOCKS", 2048), env_int("P3D_FUSED_XT", -1), env_int("P3D_FUSED_XT_TAIL", -1),
                   env_int("P3D_FUSED_TAIL_DIV", 4), env_int("P3D_FUSED_SPLIT_ROWS", 1), env_int("P3D_FUSED_SMALL16", 1),
                   env_int("P3D_COMPACT_BLOCKS", 256), env_int("P3D_COMPACT_EARLY", 3),
                   env_int("P3D_TEST_ID_LIMIT", 1 << 26), env_int("P3D_NO_CHUNK_PRE", 0),
-                  env_int("P3D_TEST_INDEX_LIMIT", 0x7fffffff)};
+                  env_int("P3D_TEST_INDEX_LIMIT", 0x7fffffff), env_int("P3D_STACK_NPARTS", -1), env_int("P3D_STACK_EARLY", -1)};
 }
 Tuning g_tuning;
 std::once_flag g_tuning_once;
@@ -1813,8 +1813,10 @@ int fused_stack_impl(const T* grids, const Dims& d, const Ws& w, float thresh, c
     const bool copy = scratch && capv > 0;
     // compaction blocks: every (item, region) is copied in `nparts` slices, `early` of them by blocks riding in the
     // counting launch (VALU-bound, HBM idle), the rest with the faces -- about two thousand blocks for the stack
-    const int nparts = copy ? std::max(2, std::min(8, 2048 / (kRegions * d.nitems))) : 1;
-    const int early = (copy && w.nchunks > 0) ? std::max(1, nparts * 3 / 8) : 0;
+    int nparts = copy ? std::max(2, std::min(8, 2048 / (kRegions * d.nitems))) : 1;
+    if (copy && tuning().stack_nparts > 0) nparts = tuning().stack_nparts;
+    int early = (copy && w.nchunks > 0) ? std::max(1, nparts * 3 / 8) : 0;
+    if (copy && w.nchunks > 0 && tuning().stack_early >= 0) early = std::min(nparts - 1, tuning().stack_early);
     if (w.nchunks > 0) {
         StageTimer tm(ST_FACES_COUNT, st);
         const CompactArgs cpe{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, early * kRegions * d.nitems, 0,
