@@ -614,15 +614,43 @@ __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr
     for (; i < nvec; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(s4 + i), d4 + i);
 }
 
+// Exclusive prefix of the chunk totals by ONE block of 1024 threads (a thread takes a run of consecutive chunks): what a
+// face tile reads instead of adding the totals in front of its chunk up when there are more than kPreMinChunks of them.
+__device__ inline void block_chunk_prefix(const u32* __restrict__ chunk_sum, int nchunks, u32* __restrict__ chunk_pre) {
+    __shared__ u32 s_wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (nchunks + 1023) / 1024;
+    const int i0 = tid * per;
+    u32 sum = 0;
+    for (int k = 0; k < per; ++k)
+        if (i0 + k < nchunks) sum += chunk_sum[i0 + k];
+    const u32 inc = wave_prefix_sum(sum);
+    if (lane == 63) s_wsum[wv] = inc;
+    __syncthreads();
+    u32 base = 0;
+    for (int w = 0; w < wv; ++w) base += s_wsum[w];
+    u32 run = base + inc - sum;
+    for (int k = 0; k < per; ++k)
+        if (i0 + k < nchunks) {
+            chunk_pre[i0 + k] = run;
+            run += chunk_sum[i0 + k];
+        }
+    __syncthreads();
+}
+__global__ void __launch_bounds__(1024) k_chunk_prefix(const u32* __restrict__ chunk_sum, int nchunks, u32* __restrict__ chunk_pre) {
+    block_chunk_prefix(chunk_sum, nchunks, chunk_pre);
+}
+
 // Totals, flags and per-item offsets of a stack of items (one block of 1024 threads, launched after the face kernel of a
 // batched call): 32 lanes per item add up its 32 cursors and its chunk totals, thread 0 then walks the items.
 // item_offsets: [nitems + 1] vertex offsets, then [nitems + 1] face offsets.
 __global__ void __launch_bounds__(1024) k_stack_finish(const u64* __restrict__ cursors, const u32* __restrict__ chunk_sum,
                                                        int nchunks, int nitems, u32 rows_limit, u32 id_limit,
                                                        int64_t* __restrict__ item_offsets, u64* __restrict__ hdr, u64* mb,
-                                                       u64 seq) {
+                                                       u64 seq, u32* __restrict__ chunk_pre) {
     __shared__ u64 s_nv[32], s_nf[32];
     __shared__ u32 s_fl[32];
+    if (chunk_pre) block_chunk_prefix(chunk_sum, nchunks, chunk_pre);
     const int tid = threadIdx.x, sub = tid & 31, grp = tid >> 5;   // 32 groups of 32 lanes
     const int cpi = nchunks / nitems;
     u64 run_v = 0, run_f = 0;
@@ -686,8 +714,7 @@ __global__ void __launch_bounds__(1024) k_stack_finish(const u64* __restrict__ c
 template <int PB>
 __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restrict__ bits, Dims d, int64_t tpp, int xw,
                                                             int cpi, u32* __restrict__ chunk_sum, u32* __restrict__ wave_off,
-                                                            u32* __restrict__ tile_tris, u32* __restrict__ chunk_pre,
-                                                            CompactArgs cp, u64* __restrict__ hdr) {
+                                                            u32* __restrict__ tile_tris, CompactArgs cp, u64* __restrict__ hdr) {
     if ((int)blockIdx.x < cp.nblocks) {  // the launch's first blocks move vertices (uniform per block)
         compact_block(cp, hdr, nullptr, 0);
         return;
@@ -719,7 +746,8 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
             Wq[i] = valid ? bits[u + d.ncz] : 0ull;
         });
         // first bit of the next chunk of both columns, all planes in one word: the next lane has them (same row);
-        // the wave's last lane loads them
+        // the wave's last lane loads them (a second memory round trip for that lane; hoisting these loads in front of the
+        // columns made the compiler wait after every pair of them -- nine round trips -- and was dropped)
         static_for<0, PB + 1>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             first |= ((u32)(Wp[i] & 1ull) | ((u32)(Wq[i] & 1ull) << 1)) << (2 * i);
@@ -790,41 +818,11 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
         }
         __syncthreads();
     }
-    // With many chunks (a stack of items) the LAST chunk block to finish turns the chunk totals into their exclusive
-    // prefix (chunk_pre), so that a face tile reads one number instead of adding up to 4096 of them (with up to
-    // kPreMinChunks chunks a tile's <= 4 loads per thread ride in its single prologue round trip, and the serial tail of
-    // this scan would cost more than it saves: +6 us here vs -2 us there at 512^3).  Completion counter = the spare word
-    // next to the call's first vertex cursor (zero when the call starts: the cursor block is cleared for every call).
-    // The totals are handed over WITHOUT agent-scope fences (a release fence writes the whole L2 back: 56 us instead of
-    // 21 for this kernel): every total is stored and loaded with agent-scope (sc1) accesses, and the store is drained
-    // before the counter is bumped (MI355X_MICROARCH.md, correctness boundaries).
-    if (chunk_pre && cp.cursors) {
-        __shared__ u32 s_last, s_scan[4];
-        const u32 nchunks = gridDim.x - (u32)cp.nblocks;
-        if (tid == 0) {
-            __hip_atomic_store(chunk_sum + chunk, running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // = s_waitcnt vmcnt(0): the store has left the CU
-            const u64 prev = __hip_atomic_fetch_add((u64*)cp.cursors + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = prev == (u64)nchunks - 1ull ? 1u : 0u;
-        }
-        __syncthreads();
-        if (s_last) {
-            const u32 per = (nchunks + kBlock - 1) / kBlock;   // <= 16 up to 4096 chunks (more only for stacks of very many items)
-            const u32 i0 = (u32)tid * per;
-            u32 sum = 0;
-            for (u32 k = 0; k < per; ++k)
-                if (i0 + k < nchunks) sum += __hip_atomic_load(chunk_sum + i0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            u32 total;
-            u32 run = block_excl_scan(sum, s_scan, &total);
-            for (u32 k = 0; k < per; ++k)
-                if (i0 + k < nchunks) {
-                    chunk_pre[i0 + k] = run;
-                    run += __hip_atomic_load(chunk_sum + i0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-        }
-    } else if (tid == 0) {
-        chunk_sum[chunk] = running;
-    }
+    // (With many chunks -- a stack of items, a very large grid -- a face tile reads the exclusive prefix of these totals
+    //  instead of adding them up: k_chunk_prefix / k_stack_finish make it, one small block between the two launches.  The
+    //  last counting block used to do that inside this launch; its hand-off -- an agent-scope store, a drained wait and a
+    //  returning atomic per block -- cost every block 1-2 us: 115 -> 90 us on the 32 x 256^3 stack.)
+    if (tid == 0) chunk_sum[chunk] = running;
 }
 
 // F = sum of the chunk totals -> header + host mailbox (the counting call and the slab path; the one-pass call lets
@@ -932,6 +930,17 @@ __device__ inline u32 rank32(u32 crossing, u32 lowm, u32 base) {   // base + cro
 #ifndef P3D_FACES_ABL   // dev-only timing ablation (wrong results): 1 = return after the staging barrier
 #define P3D_FACES_ABL 0
 #endif
+#ifndef P3D_FACES_STAMP   // dev-only: s_memtime stamps of every face wave's phases -> a debug buffer (tools/dev/faces_stamps.py)
+#define P3D_FACES_STAMP 0
+#endif
+#if P3D_FACES_STAMP
+__device__ u64* g_face_stamps = nullptr;   // [blocks * 4 waves][16]
+#define FSTAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FSTAMP_NOWAIT(k) do { stamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FSTAMP(k) do { } while (0)
+#define FSTAMP_NOWAIT(k) do { } while (0)
+#endif
 template <int N>
 __device__ inline u32 row_nibble(u32 lo, u32 hi) {   // nibble N of the 64-bit table row (lo, hi)
     if constexpr (N < 8) return (lo >> (4 * N)) & 15u;
@@ -949,9 +958,26 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     constexpr int NS = (kBlock + NHALO + 1) > 2 * (kBlock + 1) ? (kBlock + NHALO + 1) : (NHALO >= kBlock ? 2 * (kBlock + 1) : kBlock + NHALO + 1);
     __shared__ u64 s_w[2][NS + 1];                       // sign words of planes x and x+1 (read as a dword stream; one pad)
     __shared__ u32 s_e[2][3 * NS + 3];                   // per staged unit: {first id, offsets of the low half, of the high half}
-    __shared__ unsigned short s_cells[4][kWaveCells];    // per wave: active cells of the round, unit-in-tile << 6 | z
+    __shared__ u32 s_mark[4][64];                        // per wave: unit markers of the batch's cell slots
     __shared__ u32 s_ids[4][12][64];                     // per wave: vertex ids of the batch's cells' 12 edges
     __shared__ u32 s_tmp[4];
+#if P3D_FACES_STAMP
+    u64 stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    FSTAMP_NOWAIT(0);
+    const u64 rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // The kernel arguments the prologue's address arithmetic needs are touched here, together: the compiler otherwise
+    // fetches them piecemeal, basic block by basic block, and every piece is a scalar-memory wait of its own (eight in a
+    // row in front of the first vector load).
+    {
+        auto pin32 = [](u32 v) { asm volatile("" ::"s"(v)); };
+        auto pin64 = [](u64 v) { asm volatile("" ::"s"(v)); };
+        pin64((u64)d.P); pin64((u64)d.U); pin32((u32)d.ncz); pin64((u64)d.ry); pin64((u64)d.xper); pin32((u32)d.stack);
+        pin64((u64)a.tpp); pin32((u32)a.cpi); pin32((u32)a.xw_shift); pin32((u32)a.xlate); pin32((u32)a.halo_last);
+        pin32(a.div_tpp.m); pin32(a.div_xper.m); pin32(a.div_ncz.m);
+        pin64((u64)a.chunk_sum); pin64((u64)a.chunk_pre); pin64((u64)a.wave_off); pin64((u64)a.tile_tris);
+        pin64((u64)a.cursors); pin64((u64)a.rank_counts); pin64((u64)bits); pin64((u64)rec);
+    }
     const bool XLATE = a.xlate == 1 || (a.xlate == 2 && hdr[H_RECFORM] != 0ull);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // (32-bit index arithmetic by multiply-high: three divisions by run-time constants)
@@ -962,18 +988,15 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     const u32 item = d.stack ? fd_div(x32, a.div_xper) : 0u;
     const u32 xl = x32 - item * (u32)d.xper;
     if (xl == (u32)d.xper - 1u) return;   // the last plane of an item has no cell layer above it (stack of items only)
-    u32 pref = 0;
-    if (XLATE) {
-        if (a.xlate == 1) {
-            const u32 cnt = lane < kRegions ? (u32)a.cursors[(size_t)item * kCursorBlockWords + lane * kCursorStride] : 0u;
-            pref = wave_prefix_sum(cnt) - cnt;
-        } else if (lane < kRegions) {
-            pref = (u32)hdr[H_PREFIX + lane];
-        }
-    }
-    auto dense = [&](u32 v) -> u32 {
-        return XLATE ? (v & 0x3ffffffu) + (u32)__builtin_amdgcn_ds_bpermute((int)(((v >> 26) & (kRegions - 1)) << 2), (int)pref) : v;
-    };
+    // ---- prologue: every global load of the block is issued before the first wait ----
+    // One "misc" dword per lane gathers the small per-block inputs in ONE vector load (uniform addresses would become
+    // scalar loads, and every s_waitcnt lgkmcnt(0) behind one of those is a serial memory round trip -- the compiler had
+    // strung five of them in front of the staging loads: 2.9 us of a wave's 9.6, tools/dev/faces_stamps.py):
+    //   lanes 0..31  the 32 vertex-region cursors of the item (their exclusive prefix makes region-form ids dense)
+    //   lane 32      the tile's triangle count          lanes 33..36  the first face of the tile's four waves in its chunk
+    //   lane 37      the chunk's exclusive prefix (when the counting launch left one)
+    const u32 mychunk32 = item * (u32)a.cpi + (xl >> a.xw_shift) * (u32)a.tpp + (u32)tile;
+    // (multi-GPU slabs: the id bases come from the all-gathered vertex counts -- scalar loads, in front of the vector loads)
     u32 b0 = (u32)a.vid_base, bhalo = (u32)a.halo_vid_base;
     if (a.rank_counts) {
         int64_t acc = 0;
@@ -981,7 +1004,16 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
         b0 = (u32)acc;
         bhalo = (u32)(acc + a.rank_counts[(size_t)a.rank * a.rank_stride]);
     }
-    const u32 my_tris = a.tile_tris[b];
+    // (every lane has a valid address and the loads are unconditional: one basic block, so that the compiler lets all the
+    //  prologue's loads leave before it waits for the first)
+    const u32* mp = a.tile_tris + b;
+    {
+        const u32* const curp = a.xlate == 2 ? (const u32*)(hdr + H_PREFIX + (lane & 31))
+                                             : (const u32*)(a.cursors + (size_t)item * kCursorBlockWords + (lane & 31) * kCursorStride);
+        mp = (lane < kRegions && XLATE) ? curp : mp;
+        mp = (lane > 32 && lane < 37) ? a.wave_off + (size_t)b * 4 + (lane - 33) : mp;
+        mp = (lane == 37 && a.chunk_pre) ? a.chunk_pre + mychunk32 : mp;
+    }
     const int64_t p = tile * kBlock + tid;
     const int64_t y = fd_div((u32)p, a.div_ncz);   // (p < 2^31: check_dims)
     const int c = (int)(p - y * d.ncz);
@@ -997,39 +1029,80 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     const int64_t p0 = tile * kBlock;
     const bool xhalo = a.halo_last && (x + 1 == d.rx - 1);
     constexpr int NST = (NS + kBlock - 1) / kBlock;
-    u64 st_w0[NST], st_w1[NST], st_y0[NST], st_y1[NST];
-    uint2 st_r0[NST], st_r1[NST];
-    const int wave0 = wave * 64;   // (a wave skips a pass none of whose 64 entries exists: the pass behind the tile's 256
-                                   //  units stages at most NHALO + 1 entries -- one wave's worth for the short-row variant)
+    const int wave0 = wave * 64;
+    const int64_t ulast = d.U - 1;
+    const u64* wp[4 * NST];      // addresses of the staged words: per pass {plane x, plane x+1, row above in x, in x+1}
+    const uint2* rp[2 * NST];    // ... and of the two records
+    bool st_in[NST], st_up[NST];
 #pragma unroll
     for (int q = 0; q < NST; ++q) {
+        // (entries that do not exist -- behind the staged range, behind the plane, a row above the plane's last -- read a
+        //  clamped address and are masked afterwards: conditional loads made the compiler wait between them)
         const int i = tid + q * kBlock;
-        st_w0[q] = st_w1[q] = st_y0[q] = st_y1[q] = 0ull;
-        st_r0[q] = st_r1[q] = make_uint2(0u, 0u);
-        if (wave0 + q * kBlock >= nstage) continue;   // wave-uniform
         const int64_t pi = (one_range || i <= kBlock) ? p0 + i : p0 + d.ncz + (i - kBlock - 1);
-        if (i < nstage && pi < d.P) {
-            const int64_t ui = x * d.P + pi;
-            st_w0[q] = bits[ui];
-            st_w1[q] = bits[ui + d.P];
-            st_r0[q] = rec[ui];
-            st_r1[q] = rec[ui + d.P];
-            if (pi + d.ncz < d.P) {   // the row above exists (same plane)
-                st_y0[q] = bits[ui + d.ncz];
-                st_y1[q] = bits[ui + d.P + d.ncz];
-            }
-        }
+        st_in[q] = i < nstage && pi < d.P;
+        st_up[q] = st_in[q] && pi + d.ncz < d.P;   // the row above exists (same plane)
+        const int64_t ui = x * d.P + (st_in[q] ? pi : p0);      // (all idle lanes read the tile's first unit: one line)
+        const int64_t uy = st_up[q] ? ui + d.ncz : ui;
+        wp[4 * q + 0] = bits + ui;
+        wp[4 * q + 1] = bits + min(ui + d.P, ulast);
+        wp[4 * q + 2] = bits + uy;
+        wp[4 * q + 3] = bits + min(uy + d.P, ulast);
+        rp[2 * q + 0] = rec + ui;
+        rp[2 * q + 1] = rec + min(ui + d.P, ulast);
+    }
+    // this thread's share of the chunk totals in front of its chunk (at most kPreMinChunks = 1024 chunks without a prefix:
+    // four independent loads; more only under the P3D_NO_CHUNK_PRE test switch, added up behind the staging)
+    const u32* cp4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cp4[k] = a.chunk_sum + min((u32)tid + (u32)k * kBlock, mychunk32);
+    // ---- the loads: one batch ----
+    const u32 misc = *mp;
+    u32 part[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) part[k] = *cp4[k];
+    u64 lw[4 * NST];
+    uint2 lr[2 * NST];
+#pragma unroll
+    for (int q = 0; q < 4 * NST; ++q) lw[q] = *wp[q];
+#pragma unroll
+    for (int q = 0; q < 2 * NST; ++q) lr[q] = *rp[q];
+    FSTAMP_NOWAIT(1);   // all prologue loads issued
+    // (a tile without triangles leaves only in front of the barrier, behind the staging: a branch HERE lets the compiler
+    //  sink every load that follows in program order below it, i.e. behind the wait for this first one)
+    const u32 my_tris = (u32)__builtin_amdgcn_readlane((int)misc, 32);
+    FSTAMP(2);          // ... and returned
+    u64 st_w0[NST], st_w1[NST], st_y0[NST], st_y1[NST];
+    uint2 st_r0[NST], st_r1[NST];
+#pragma unroll
+    for (int q = 0; q < NST; ++q) {
+        st_w0[q] = st_in[q] ? lw[4 * q + 0] : 0ull;
+        st_w1[q] = st_in[q] ? lw[4 * q + 1] : 0ull;
+        st_y0[q] = st_up[q] ? lw[4 * q + 2] : 0ull;
+        st_y1[q] = st_up[q] ? lw[4 * q + 3] : 0ull;
+        st_r0[q] = st_in[q] ? lr[2 * q + 0] : make_uint2(0u, 0u);
+        st_r1[q] = st_in[q] ? lr[2 * q + 1] : make_uint2(0u, 0u);
     }
     u32 cs = 0;
-    {
-        const int64_t mychunk = (int64_t)(item * (u32)a.cpi + (xl >> a.xw_shift) * (u32)a.tpp) + tile;
-        if (a.chunk_pre) {
-            if (tid == 0) cs = a.chunk_pre[mychunk];
-        } else {
-            for (int64_t i = tid; i < mychunk; i += kBlock) cs += a.chunk_sum[i];
+    if (!a.chunk_pre) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cs += ((u32)tid + (u32)k * kBlock < mychunk32) ? part[k] : 0u;
+        if (mychunk32 > 4u * kBlock)
+            for (u32 i = (u32)tid + 4u * kBlock; i < mychunk32; i += kBlock) cs += a.chunk_sum[i];
+    }
+    u32 pref = 0;
+    if (XLATE) {
+        if (a.xlate == 1) {
+            const u32 cnt = lane < kRegions ? misc : 0u;
+            pref = wave_prefix_sum(cnt) - cnt;
+        } else if (lane < kRegions) {
+            pref = misc;
         }
     }
-    if (my_tris == 0u) return;
+    auto dense = [&](u32 v) -> u32 {
+        return XLATE ? (v & 0x3ffffffu) + (u32)__builtin_amdgcn_ds_bpermute((int)(((v >> 26) & (kRegions - 1)) << 2), (int)pref) : v;
+    };
+    if (a.chunk_pre) cs = lane == 37 && wave == 0 ? misc : 0u;
     u32* const E0 = s_e[0];
     u32* const E1 = s_e[1];
 #pragma unroll
@@ -1064,12 +1137,16 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
         cs = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum(cs), 63);
         if (lane == 0) s_tmp[wave] = cs;
     }
+    FSTAMP(3);          // staged (LDS writes done)
+    if (my_tris == 0u) return;   // (block-uniform)
     __syncthreads();  // the only block barrier: staging done (no store is in flight yet)
+    FSTAMP_NOWAIT(4);   // barrier passed
 #if P3D_FACES_ABL == 1
     return;
 #endif
     // first face of this wave and the capacity, relative to it (a wave-tile emits at most 64 * 64 * 5 faces)
-    const u32 wrun0 = (u32)__builtin_amdgcn_readfirstlane((int)((s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3]) + a.wave_off[b * 4 + wave]));
+    const u32 wrun0 = (u32)__builtin_amdgcn_readfirstlane((int)(s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3])) +
+                      (u32)__builtin_amdgcn_readlane((int)misc, 33 + wave);
     const u32 cap32 = (u32)min(cap_faces, (int64_t)0x7fffffff);
     const u32 cap_rel = cap32 > wrun0 ? cap32 - wrun0 : 0u;
     int32_t* const wfaces = faces + (size_t)wrun0 * 3;   // (wave-uniform base: the stores take a 32-bit offset)
@@ -1090,44 +1167,46 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
         }
         if (valid) act_all = orr & ~andd & zedge(d, c);
     }
-    static_assert(kWaveCells >= 256, "a 4-voxel z slice of a wave holds up to 256 cells");
-    int wbits = 64;
-    {
-        u32 fullest = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum((u32)popc64(act_all)), 63);
-        while (fullest > (u32)kWaveCells && wbits > 4) {   // (wave-uniform)
-            wbits >>= 1;
-            fullest = 0;
-            for (int sl = 0; sl < 64; sl += wbits) {
-                const u64 m = ((1ull << wbits) - 1ull) << sl;
-                fullest = max(fullest, (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum((u32)popc64(act_all & m)), 63));
-            }
-        }
-    }
-    const int rounds = 64 / wbits;
-    unsigned short* const cells = s_cells[wave];
+    // phase B (lane = unit): the wave's active cells are numbered unit by unit, ascending z (no list is built: a list
+    // needs one loop trip per active cell of the wave's FULLEST unit -- tens of trips where the surface runs along z --
+    // and cost 1-2 us of a wave's 9.6, tools/dev/faces_stamps.py)
+    const u32 pc = (u32)popc64(act_all);
+    const u32 inc0 = wave_prefix_sum(pc);
+    const u32 na = (u32)__builtin_amdgcn_readlane((int)inc0, 63);
+    const u32 off = inc0 - pc;                      // this unit's cells are slots [off, off + pc)
+    const u32 act_lo = (u32)act_all, act_hi = (u32)(act_all >> 32);
+    const bool owner = pc > 0u;
+    u32* const mark = s_mark[wave];
     const u32* const W0 = (const u32*)s_w[0];
     const u32* const W1 = (const u32*)s_w[1];
     u32* const ids = &s_ids[wave][0][lane];   // this lane's column: edge e at ids[e * 64]
-
-    for (int rd = 0; rd < rounds; ++rd) {
-        u64 act = rounds == 1 ? act_all : (act_all & (((1ull << wbits) - 1ull) << (wbits * rd)));
-        // phase B (lane = unit): dense list of the wave's active cells
-        const u32 pc = (u32)popc64(act);
-        const u32 inc0 = wave_prefix_sum(pc);
-        const u32 na = (u32)__builtin_amdgcn_readlane((int)inc0, 63);
-        u32 off = inc0 - pc;
-        while (act) {
-            const int z = __ffsll((long long)act) - 1;
-            act &= act - 1;
-            cells[off++] = (unsigned short)((tid << 6) | z);
-        }
-        wave_lds_sync();
-
+#if P3D_FACES_STAMP
+    FSTAMP(5);
+    stamp[10] = na;
+#endif
+    {
         for (u32 i0 = 0; i0 < na; i0 += 64) {
-            // phase C (lane = cell).  Every listed cell has a sign change, i.e. at least one triangle.
-            const u32 i = i0 + lane;
-            const bool on = i < na;
-            const u32 cell = on ? (u32)cells[i] : (u32)cells[i0];   // (idle lanes shadow the batch's first cell)
+            // phase C (lane = cell slot i0 + lane).  Its unit: the units that start inside this batch drop a marker on
+            // their first slot, a prefix max spreads it (slots in front of the first marker belong to the last unit that
+            // starts before the batch); its z: the (slot - off)-th set bit of that unit's active word.
+            mark[lane] = 0u;
+            if (owner && off >= i0 && off < i0 + 64u) mark[off - i0] = (u32)lane + 1u;
+            wave_lds_sync();
+            const u32 mk = mark[lane];
+            const u64 before = __ballot(owner && off < i0);
+            const u32 prev = before ? 63u - (u32)__builtin_clzll(before) : 0u;
+            const u32 um = wave_prefix_max(mk);
+            const u32 tl = (um ? um : prev + 1u) - 1u;
+            const bool on = i0 + (u32)lane < na;
+            const int tsel = (int)(tl << 2);
+            const u32 u_lo = (u32)__builtin_amdgcn_ds_bpermute(tsel, (int)act_lo);
+            const u32 u_hi = (u32)__builtin_amdgcn_ds_bpermute(tsel, (int)act_hi);
+            const u32 u_off = (u32)__builtin_amdgcn_ds_bpermute(tsel, (int)off);
+            // (idle lanes of the last batch shadow the first active cell of the batch's last unit: a valid active cell)
+            const u32 rnk = on ? i0 + (u32)lane - u_off : 0u;
+            const u32 cz = select_bit(((u64)u_hi << 32) | u_lo, rnk);
+            const u32 cell = (((u32)wave0 + tl) << 6) | cz;
+            // Every listed cell has a sign change, i.e. at least one triangle.
             const u32 t = cell >> 6, zz = cell & 31u, D = cell >> 5, Dh = D + 2u * (u32)hoff;
             const bool z63 = (cell & 63u) == 63u;
             // the dword windows of the four columns: a = the half unit holding z, b = the dword behind it
@@ -1146,6 +1225,9 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
             const u64 row = g_tri_rows.r[mask];   // (2 KiB, hot in the vector L1)
             const u32 row_lo = (u32)row, row_hi = (u32)(row >> 32);
             const u32 nt = on ? row_hi >> 28 : 0u;
+#if P3D_FACES_STAMP
+            if (i0 == 0) { asm volatile("" :: "v"(nt)); FSTAMP(6); }   // first batch: header (windows, records, table row) in
+#endif
             // crossing words of this half (axis 0: columns (x,y) and (x,y+1); axis 1: (x,y) and (x+1,y); axis 2: all four)
             const u32 lowm = (1u << zz) - 1u;
             const u32 Cx0 = a0 ^ a1, Cx3 = a3 ^ a2, Cy0 = a0 ^ a3, Cy1 = a1 ^ a2;
@@ -1179,6 +1261,9 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
             ids[9 * 64] = id9;
             ids[10 * 64] = id10;
             ids[11 * 64] = id11;
+#if P3D_FACES_STAMP
+            if (i0 == 0) FSTAMP(7);   // first batch: ids computed and written
+#endif
             // the batch's triangles, k-th triangle of every cell together: the lanes that have one write a DENSE run.
             // The three ids come back out of the lane's LDS column by table index.
             // The ids of the first two triangles are read back before the first store (most cells have two; a cell with one
@@ -1220,9 +1305,24 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
                 }
                 rel += (u32)popc64(have);
             });
+#if P3D_FACES_STAMP
+            if (i0 == 0) FSTAMP_NOWAIT(8);   // first batch: stores issued
+#endif
         }
-        wave_lds_sync();   // the next round rewrites the cell list
     }
+#if P3D_FACES_STAMP
+    FSTAMP_NOWAIT(9);
+    stamp[11] = rel;
+    if (lane == 0 && g_face_stamps) {
+        u64* o = g_face_stamps + ((size_t)b * 4 + wave) * 16;
+        for (int k = 0; k < 12; ++k) o[k] = stamp[k];
+        o[12] = __builtin_amdgcn_s_memrealtime();
+        u32 xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[13] = xcc;
+        o[14] = rt0;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1462,13 +1562,13 @@ bool mailbox_wait(const void* ws, u64* nv, u64* nf, u64* flags) {
 
 // the counting launch: sub-batches of 8 planes, or of 4 for the 4-plane chunks of small grids
 void launch_count_walk(dim3 grid, hipStream_t st, const u64* bits, const Dims& d, const Ws& w, u32* csum, u32* woff,
-                       u32* tile_tris, u32* cpre, const CompactArgs& cp, u64* hdr) {
+                       u32* tile_tris, const CompactArgs& cp, u64* hdr) {
     if (w.xw == 4)
         hipLaunchKernelGGL(k_face_count_walk<4>, grid, dim3(kBlock), 0, st, bits, d, w.tpp, w.xw, (int)w.cpi, csum, woff,
-                           tile_tris, cpre, cp, hdr);
+                           tile_tris, cp, hdr);
     else
         hipLaunchKernelGGL(k_face_count_walk<P3D_COUNT_PB>, grid, dim3(kBlock), 0, st, bits, d, w.tpp, w.xw, (int)w.cpi,
-                           csum, woff, tile_tris, cpre, cp, hdr);
+                           csum, woff, tile_tris, cp, hdr);
 }
 
 // the face launch: with `faces_here` one block per face tile, else the compaction blocks only
@@ -1523,7 +1623,7 @@ int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3
     if (w.nchunks > 0) {
         StageTimer tm(ST_FACES_COUNT, st);
         const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr, 1u << 26, 1, nullptr};
-        launch_count_walk(dim3((u32)w.nchunks), st, bits, d, w, csum, woff, (u32*)(ws + w.tile_tris), (u32*)nullptr, none, hdr);
+        launch_count_walk(dim3((u32)w.nchunks), st, bits, d, w, csum, woff, (u32*)(ws + w.tile_tris), none, hdr);
     }
     {
         StageTimer tm(ST_SCAN_F, st);
@@ -1759,7 +1859,8 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         StageTimer tm(ST_FACES_COUNT, st);
         const CompactArgs cpe{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, early * kRegions, 0, nparts, 0,
                               csum, (int)w.nchunks, cursors, id_limit, 1, nullptr};
-        launch_count_walk(dim3((u32)(w.nchunks + cpe.nblocks)), st, bits, d, w, csum, woff, (u32*)(ws + w.tile_tris), cpre, cpe, hdr);
+        launch_count_walk(dim3((u32)(w.nchunks + cpe.nblocks)), st, bits, d, w, csum, woff, (u32*)(ws + w.tile_tris), cpe, hdr);
+        if (cpre) hipLaunchKernelGGL(k_chunk_prefix, dim3(1), dim3(1024), 0, st, csum, (int)w.nchunks, cpre);
     }
     if (part == 4) {  // totals to the host now; the faces (and the rest of the vertex copy) follow in part 5
         StageTimer tm(ST_SCAN_F, st);
@@ -1821,7 +1922,7 @@ int fused_stack_impl(const T* grids, const Dims& d, const Ws& w, float thresh, c
         StageTimer tm(ST_FACES_COUNT, st);
         const CompactArgs cpe{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, early * kRegions * d.nitems, 0,
                               nparts, 0, csum, (int)w.nchunks, cursors, id_limit, d.nitems, item_offsets};
-        launch_count_walk(dim3((u32)(w.nchunks + cpe.nblocks)), st, bits, d, w, csum, woff, (u32*)(ws + w.tile_tris), cpre, cpe, hdr);
+        launch_count_walk(dim3((u32)(w.nchunks + cpe.nblocks)), st, bits, d, w, csum, woff, (u32*)(ws + w.tile_tris), cpe, hdr);
     }
     const FaceArgs a{1, 0, 0, 0, nullptr, 0, 1, w.tpp, w.xw, (int)w.cpi, csum, cpre, woff,
                      (const u32*)(ws + w.tile_tris), cursors, nullptr, 0};
@@ -1832,7 +1933,7 @@ int fused_stack_impl(const T* grids, const Dims& d, const Ws& w, float thresh, c
     // final after the counting launch, and the host then sizes its tensors and queues the next call while the faces are
     // still being written (40 us of idle GPU per batch when this ran last)
     hipLaunchKernelGGL(k_stack_finish, dim3(1), dim3(1024), 0, st, cursors, csum, (int)w.nchunks, d.nitems,
-                       scratch ? store_rows : region_rows, id_limit, item_offsets, hdr, mb, seq);
+                       scratch ? store_rows : region_rows, id_limit, item_offsets, hdr, mb, seq, cpre);
     {
         StageTimer tm(ST_EMIT_FACES, st);
         launch_faces(d, w, bits, rec, a, cp, hdr, faces, capf, w.nb_f > 0 && capf > 0, st);
@@ -1983,6 +2084,14 @@ int p3d_mc_debug_layout(int64_t rx, int64_t ry, int64_t rz, size_t* off_bits, si
     *chunks_per_row = d.ncz;
     return P3D_OK;
 }
+
+#if P3D_FACES_STAMP
+int p3d_mc_debug_face_stamps(void* buf) {   // dev build only: where k_faces leaves its per-wave phase stamps
+    u64* p = (u64*)buf;
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_face_stamps), &p, sizeof(p)));
+    return P3D_OK;
+}
+#endif
 
 int p3d_mc_reload_tuning(void) {   // dev / test hook: re-read the P3D_* knobs (not for use beside running calls)
     (void)tuning();
