@@ -525,9 +525,13 @@ typedef float F4A __attribute__((ext_vector_type(4)));
 // A stack of items (a batch of grids) has one cursor block and 32 scratch regions per item: the launch's compaction
 // blocks are split evenly over the items (c.nblocks = nitems * slices * 32) and an item's vertices land behind those of
 // the items before it; the totals and per-item offsets of a stack are written by k_stack_finish, not here.
-__device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr, u64* mb, u64 seq) {
-    __shared__ u64 s_cur[kRegions], s_pre[kRegions];
-    __shared__ u64 s_item_base, s_red[4];
+constexpr int kCompactSmemWords = 2 * kRegions + 1 + 4;   // u64 words of LDS a compaction block needs (from its caller:
+                                                          // the face kernel lends a corner of its id columns)
+__device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr, u64* mb, u64 seq, u64* smem) {
+    u64* const s_cur = smem;
+    u64* const s_pre = smem + kRegions;
+    u64& s_item_base = smem[2 * kRegions];
+    u64* const s_red = smem + 2 * kRegions + 1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int nitems = c.nitems > 0 ? c.nitems : 1;
     const int per_item = c.nblocks / nitems;                       // compaction blocks per item (multiple of 32)
@@ -716,7 +720,8 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
                                                             int cpi, u32* __restrict__ chunk_sum, u32* __restrict__ wave_off,
                                                             u32* __restrict__ tile_tris, CompactArgs cp, u64* __restrict__ hdr) {
     if ((int)blockIdx.x < cp.nblocks) {  // the launch's first blocks move vertices (uniform per block)
-        compact_block(cp, hdr, nullptr, 0);
+        __shared__ u64 s_cb[kCompactSmemWords];
+        compact_block(cp, hdr, nullptr, 0, s_cb);
         return;
     }
     __shared__ u32 s_part[PB][4];
@@ -951,16 +956,21 @@ template <int NHALO>
 __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, const uint2* __restrict__ rec, Dims d,
                                                    FaceArgs a, CompactArgs cp, u64* __restrict__ hdr,
                                                    int32_t* __restrict__ faces, int64_t cap_faces) {
+    constexpr int NS = (kBlock + NHALO + 1) > 2 * (kBlock + 1) ? (kBlock + NHALO + 1) : (NHALO >= kBlock ? 2 * (kBlock + 1) : kBlock + NHALO + 1);
+    // LDS: 22.2 KiB with NHALO = 32 -> SEVEN tiles per CU (23 405 B is the limit; the sixth came with the case table moving
+    // to global memory, the seventh with the three savings noted below)
+    __shared__ u64 s_w[2][NS + 1];                       // sign words of planes x and x+1 (read as a dword stream; one pad)
+    __shared__ u32 s_e0[3 * NS + 3];                     // plane x, per staged unit: {first id, offsets of the low half, of the high half}
+    __shared__ u32 s_e1[2 * NS + 2];                     // plane x+1: {first id, y / z offsets of both halves in four bytes} (its x
+                                                         // edges belong to the next cell layer: 2 dwords instead of 3)
+    __shared__ u32 s_ids[4][12][64];                     // per wave: vertex ids of the batch's cells' 12 edges; row 0 doubles as
+                                                         // the batch's unit markers (read before the ids are written), and the
+                                                         // launch's compaction blocks borrow a corner as their scratch
+    __shared__ u32 s_tmp[4];
     if ((int)blockIdx.x < cp.nblocks) {  // the launch's first blocks move the vertices (uniform per block)
-        compact_block(cp, hdr, a.mb, a.seq);
+        compact_block(cp, hdr, a.mb, a.seq, (u64*)&s_ids[0][0][0]);
         return;
     }
-    constexpr int NS = (kBlock + NHALO + 1) > 2 * (kBlock + 1) ? (kBlock + NHALO + 1) : (NHALO >= kBlock ? 2 * (kBlock + 1) : kBlock + NHALO + 1);
-    __shared__ u64 s_w[2][NS + 1];                       // sign words of planes x and x+1 (read as a dword stream; one pad)
-    __shared__ u32 s_e[2][3 * NS + 3];                   // per staged unit: {first id, offsets of the low half, of the high half}
-    __shared__ u32 s_mark[4][64];                        // per wave: unit markers of the batch's cell slots
-    __shared__ u32 s_ids[4][12][64];                     // per wave: vertex ids of the batch's cells' 12 edges
-    __shared__ u32 s_tmp[4];
 #if P3D_FACES_STAMP
     u64 stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     FSTAMP_NOWAIT(0);
@@ -1103,8 +1113,8 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
         return XLATE ? (v & 0x3ffffffu) + (u32)__builtin_amdgcn_ds_bpermute((int)(((v >> 26) & (kRegions - 1)) << 2), (int)pref) : v;
     };
     if (a.chunk_pre) cs = lane == 37 && wave == 0 ? misc : 0u;
-    u32* const E0 = s_e[0];
-    u32* const E1 = s_e[1];
+    u32* const E0 = s_e0;
+    u32* const E1 = s_e1;
 #pragma unroll
     for (int q = 0; q < NST; ++q) {   // (wave-uniform trip count: the translation shuffles across the wave's lanes)
         const int i = tid + q * kBlock;
@@ -1124,9 +1134,8 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
             E0[3 * i] = base0;
             E0[3 * i + 1] = (oY0 << 8) | (oZ0 << 16);
             E0[3 * i + 2] = pX | ((oY0 + pY0) << 8) | ((oZ0 + pZ0) << 16);
-            E1[3 * i] = base1;
-            E1[3 * i + 1] = (oY1 << 8) | (oZ1 << 16);
-            E1[3 * i + 2] = ((oY1 + pY1) << 8) | ((oZ1 + pZ1) << 16);
+            E1[2 * i] = base1;
+            E1[2 * i + 1] = oY1 | (oZ1 << 8) | ((oY1 + pY1) << 16) | ((oZ1 + pZ1) << 24);   // (oY <= 96, oZ <= 160)
         }
     }
     if (tid == 0) {   // the pad dword behind the last staged unit (read by a window at z >= 32 of that unit, never used)
@@ -1176,7 +1185,7 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     const u32 off = inc0 - pc;                      // this unit's cells are slots [off, off + pc)
     const u32 act_lo = (u32)act_all, act_hi = (u32)(act_all >> 32);
     const bool owner = pc > 0u;
-    u32* const mark = s_mark[wave];
+    u32* const mark = &s_ids[wave][0][0];
     const u32* const W0 = (const u32*)s_w[0];
     const u32* const W1 = (const u32*)s_w[1];
     u32* const ids = &s_ids[wave][0][lane];   // this lane's column: edge e at ids[e * 64]
@@ -1215,9 +1224,10 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
             // per-half id records: {base, offsets of this half}; the next unit's {base, low-half offsets} for z = 63
             const u32 hsel = 1u + ((cell >> 5) & 1u);
             const u32 th = t + (u32)hoff;
-            const u32 B0 = E0[3 * t], O0 = E0[3 * t + hsel], B1 = E1[3 * t], O1 = E1[3 * t + hsel];
-            const u32 B3 = E0[3 * th], O3 = E0[3 * th + hsel], B2 = E1[3 * th], O2 = E1[3 * th + hsel];
-            const u32 N0 = E0[3 * t + 3], NO0 = E0[3 * t + 4], N1 = E1[3 * t + 3], NO1 = E1[3 * t + 4], N3 = E0[3 * th + 3];
+            const u32 hsh = (cell >> 1) & 16u;   // plane x+1: the half's two offset bytes sit at bit 0 or bit 16
+            const u32 B0 = E0[3 * t], O0 = E0[3 * t + hsel], B1 = E1[2 * t], O1 = E1[2 * t + 1] >> hsh;
+            const u32 B3 = E0[3 * th], O3 = E0[3 * th + hsel], B2 = E1[2 * th], O2 = E1[2 * th + 1] >> hsh;
+            const u32 N0 = E0[3 * t + 3], NO0 = E0[3 * t + 4], N1 = E1[2 * t + 2], NO1 = E1[2 * t + 3], N3 = E0[3 * th + 3];
             // corner mask (interleaved): bits z and z+1 of every column
             const u32 t0 = __builtin_amdgcn_alignbit(c0, a0, zz), t1 = __builtin_amdgcn_alignbit(c1, a1, zz);
             const u32 t2 = __builtin_amdgcn_alignbit(c2, a2, zz), t3 = __builtin_amdgcn_alignbit(c3, a3, zz);
@@ -1237,9 +1247,9 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
             const u32 id0 = rank32(Cx0, lowm, add_byte0(B0, O0));
             const u32 id3 = rank32(Cy0, lowm, add_byte1(B0, O0));
             const u32 id8 = rank32(Cz0, lowm, add_byte2(B0, O0));
-            const u32 id1 = rank32(Cy1, lowm, add_byte1(B1, O1));
-            const u32 id9 = rank32(Cz1, lowm, add_byte2(B1, O1));
-            const u32 id10 = rank32(Cz2, lowm, add_byte2(B2, O2));
+            const u32 id1 = rank32(Cy1, lowm, add_byte0(B1, O1));
+            const u32 id9 = rank32(Cz1, lowm, add_byte1(B1, O1));
+            const u32 id10 = rank32(Cz2, lowm, add_byte1(B2, O2));
             const u32 id2 = rank32(Cx3, lowm, add_byte0(B3, O3));
             const u32 id11 = rank32(Cz3, lowm, add_byte2(B3, O3));
             // edges at z+1: one more if the edge at z crosses (mask bit 2k = column k at z); at z = 63 they are the
@@ -1247,7 +1257,7 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
             const u32 q = mask ^ (mask >> 2), r = mask ^ (mask >> 6);
             const u32 id4 = z63 ? N0 : id0 + (q & 1u);
             const u32 id7 = z63 ? add_byte1(N0, NO0) : id3 + (r & 1u);
-            const u32 id5 = z63 ? add_byte1(N1, NO1) : id1 + ((q >> 2) & 1u);
+            const u32 id5 = z63 ? add_byte0(N1, NO1) : id1 + ((q >> 2) & 1u);
             const u32 id6 = z63 ? N3 : id2 + ((q >> 4) & 1u);
             ids[0 * 64] = id0;
             ids[1 * 64] = id1;
