@@ -1036,30 +1036,29 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     const bool one_range = d.ncz <= NHALO;
     const int hoff = one_range ? d.ncz : kBlock + 1;
     const int nstage = one_range ? kBlock + d.ncz + 1 : 2 * (kBlock + 1);
-    const int64_t p0 = tile * kBlock;
+    const u32 p0 = (u32)tile * kBlock;
     const bool xhalo = a.halo_last && (x + 1 == d.rx - 1);
     constexpr int NST = (NS + kBlock - 1) / kBlock;
     const int wave0 = wave * 64;
-    const int64_t ulast = d.U - 1;
-    const u64* wp[4 * NST];      // addresses of the staged words: per pass {plane x, plane x+1, row above in x, in x+1}
-    const uint2* rp[2 * NST];    // ... and of the two records
+    // plane bases are block-uniform (scalar registers); a lane adds a 32-bit unit offset inside the plane (check_dims: a
+    // plane has fewer than 2^29 units) -- no 64-bit vector arithmetic on the 17 addresses of the prologue
+    const u64* const bw0 = bits + x * d.P;
+    const u64* const bw1 = bw0 + d.P;          // (plane x + 1 exists: the last cell layer is x = rx - 2)
+    const uint2* const br0 = rec + x * d.P;
+    const uint2* const br1 = br0 + d.P;
+    u32 so[NST], sy[NST];        // offsets of the staged unit and of the unit one row up (or the unit itself when there is none)
     bool st_in[NST], st_up[NST];
 #pragma unroll
     for (int q = 0; q < NST; ++q) {
         // (entries that do not exist -- behind the staged range, behind the plane, a row above the plane's last -- read a
-        //  clamped address and are masked afterwards: conditional loads made the compiler wait between them)
-        const int i = tid + q * kBlock;
-        const int64_t pi = (one_range || i <= kBlock) ? p0 + i : p0 + d.ncz + (i - kBlock - 1);
-        st_in[q] = i < nstage && pi < d.P;
-        st_up[q] = st_in[q] && pi + d.ncz < d.P;   // the row above exists (same plane)
-        const int64_t ui = x * d.P + (st_in[q] ? pi : p0);      // (all idle lanes read the tile's first unit: one line)
-        const int64_t uy = st_up[q] ? ui + d.ncz : ui;
-        wp[4 * q + 0] = bits + ui;
-        wp[4 * q + 1] = bits + min(ui + d.P, ulast);
-        wp[4 * q + 2] = bits + uy;
-        wp[4 * q + 3] = bits + min(uy + d.P, ulast);
-        rp[2 * q + 0] = rec + ui;
-        rp[2 * q + 1] = rec + min(ui + d.P, ulast);
+        //  valid address and are masked afterwards: conditional loads made the compiler wait between them; all idle lanes
+        //  read the tile's first unit: one line)
+        const u32 i = (u32)tid + (u32)q * kBlock;
+        const u32 pi = (one_range || i <= (u32)kBlock) ? p0 + i : p0 + (u32)d.ncz + (i - (u32)kBlock - 1u);
+        st_in[q] = i < (u32)nstage && pi < (u32)d.P;
+        st_up[q] = st_in[q] && pi + (u32)d.ncz < (u32)d.P;   // the row above exists (same plane)
+        so[q] = st_in[q] ? pi : p0;
+        sy[q] = st_up[q] ? so[q] + (u32)d.ncz : so[q];
     }
     // this thread's share of the chunk totals in front of its chunk (at most kPreMinChunks = 1024 chunks without a prefix:
     // four independent loads; more only under the P3D_NO_CHUNK_PRE test switch, added up behind the staging)
@@ -1074,9 +1073,14 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     u64 lw[4 * NST];
     uint2 lr[2 * NST];
 #pragma unroll
-    for (int q = 0; q < 4 * NST; ++q) lw[q] = *wp[q];
-#pragma unroll
-    for (int q = 0; q < 2 * NST; ++q) lr[q] = *rp[q];
+    for (int q = 0; q < NST; ++q) {
+        lw[4 * q + 0] = bw0[so[q]];
+        lw[4 * q + 1] = bw1[so[q]];
+        lw[4 * q + 2] = bw0[sy[q]];
+        lw[4 * q + 3] = bw1[sy[q]];
+        lr[2 * q + 0] = br0[so[q]];
+        lr[2 * q + 1] = br1[so[q]];
+    }
     FSTAMP_NOWAIT(1);   // all prologue loads issued
     // (a tile without triangles leaves only in front of the barrier, behind the staging: a branch HERE lets the compiler
     //  sink every load that follows in program order below it, i.e. behind the wait for this first one)
@@ -1228,6 +1232,9 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
             const u32 B0 = E0[3 * t], O0 = E0[3 * t + hsel], B1 = E1[2 * t], O1 = E1[2 * t + 1] >> hsh;
             const u32 B3 = E0[3 * th], O3 = E0[3 * th + hsel], B2 = E1[2 * th], O2 = E1[2 * th + 1] >> hsh;
             const u32 N0 = E0[3 * t + 3], NO0 = E0[3 * t + 4], N1 = E1[2 * t + 2], NO1 = E1[2 * t + 3], N3 = E0[3 * th + 3];
+            // (touched here so that the five reads leave with the others: left to itself the compiler sinks them into a
+            //  divergent "some lane has z = 63" branch -- true in most batches -- with a wait of its own inside)
+            asm volatile("" ::"v"(N0), "v"(NO0), "v"(N1), "v"(NO1), "v"(N3));
             // corner mask (interleaved): bits z and z+1 of every column
             const u32 t0 = __builtin_amdgcn_alignbit(c0, a0, zz), t1 = __builtin_amdgcn_alignbit(c1, a1, zz);
             const u32 t2 = __builtin_amdgcn_alignbit(c2, a2, zz), t3 = __builtin_amdgcn_alignbit(c3, a3, zz);
