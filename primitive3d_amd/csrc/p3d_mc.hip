@@ -1229,9 +1229,10 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
             const u32 hsel = 1u + ((cell >> 5) & 1u);
             const u32 th = t + (u32)hoff;
             const u32 hsh = (cell >> 1) & 16u;   // plane x+1: the half's two offset bytes sit at bit 0 or bit 16
-            const u32 B0 = E0[3 * t], O0 = E0[3 * t + hsel], B1 = E1[2 * t], O1 = E1[2 * t + 1] >> hsh;
-            const u32 B3 = E0[3 * th], O3 = E0[3 * th + hsel], B2 = E1[2 * th], O2 = E1[2 * th + 1] >> hsh;
-            const u32 N0 = E0[3 * t + 3], NO0 = E0[3 * t + 4], N1 = E1[2 * t + 2], NO1 = E1[2 * t + 3], N3 = E0[3 * th + 3];
+            const u32 e3 = __umul24(t, 3u), eh3 = __umul24(th, 3u);   // (v_mul_u32_u24: full rate; a 32-bit multiply is not)
+            const u32 B0 = E0[e3], O0 = E0[e3 + hsel], B1 = E1[2 * t], O1 = E1[2 * t + 1] >> hsh;
+            const u32 B3 = E0[eh3], O3 = E0[eh3 + hsel], B2 = E1[2 * th], O2 = E1[2 * th + 1] >> hsh;
+            const u32 N0 = E0[e3 + 3], NO0 = E0[e3 + 4], N1 = E1[2 * t + 2], NO1 = E1[2 * t + 3], N3 = E0[eh3 + 3];
             // (touched here so that the five reads leave with the others: left to itself the compiler sinks them into a
             //  divergent "some lane has z = 63" branch -- true in most batches -- with a wait of its own inside)
             asm volatile("" ::"v"(N0), "v"(NO0), "v"(N1), "v"(NO1), "v"(N3));
@@ -1262,10 +1263,15 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
             // edges at z+1: one more if the edge at z crosses (mask bit 2k = column k at z); at z = 63 they are the
             // first ids of the next chunk of the row
             const u32 q = mask ^ (mask >> 2), r = mask ^ (mask >> 6);
-            const u32 id4 = z63 ? N0 : id0 + (q & 1u);
-            const u32 id7 = z63 ? add_byte1(N0, NO0) : id3 + (r & 1u);
-            const u32 id5 = z63 ? add_byte0(N1, NO1) : id1 + ((q >> 2) & 1u);
-            const u32 id6 = z63 ? N3 : id2 + ((q >> 4) & 1u);
+            // (both sides are computed and pinned, then selected: left alone the compiler turns every one of these into a
+            //  divergent branch pair)
+            u32 a4 = id0 + (q & 1u), a7 = id3 + (r & 1u), a5 = id1 + ((q >> 2) & 1u), a6 = id2 + ((q >> 4) & 1u);
+            u32 n7 = add_byte1(N0, NO0), n5 = add_byte0(N1, NO1);
+            asm volatile("" : "+v"(a4), "+v"(a7), "+v"(a5), "+v"(a6), "+v"(n7), "+v"(n5));
+            const u32 id4 = z63 ? N0 : a4;
+            const u32 id7 = z63 ? n7 : a7;
+            const u32 id5 = z63 ? n5 : a5;
+            const u32 id6 = z63 ? N3 : a6;
             ids[0 * 64] = id0;
             ids[1 * 64] = id1;
             ids[2 * 64] = id2;
@@ -1296,7 +1302,7 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
             {   // k = 0: every listed cell has one
                 const u64 have = __ballot(on);
                 const u32 f = __builtin_amdgcn_mbcnt_hi((u32)(have >> 32), __builtin_amdgcn_mbcnt_lo((u32)have, rel));
-                if (on && f < cap_rel) __builtin_nontemporal_store(tri0, (i3u*)(wfaces + f * 3u));
+                if (on && f < cap_rel) __builtin_nontemporal_store(tri0, (i3u*)((char*)wfaces + __umul24(f, 12u)));
                 rel += (u32)popc64(have);
             }
             bool go = true;
@@ -1318,7 +1324,7 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
                         tv.y = (int32_t)ids[row_nibble<3 * k + 1>(row_lo, row_hi) * 64];
                         tv.z = (int32_t)ids[row_nibble<3 * k + 2>(row_lo, row_hi) * 64];
                     }
-                    __builtin_nontemporal_store(tv, (i3u*)(wfaces + f * 3u));
+                    __builtin_nontemporal_store(tv, (i3u*)((char*)wfaces + __umul24(f, 12u)));
                 }
                 rel += (u32)popc64(have);
             });
