@@ -343,6 +343,8 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_kernel_ms": round(avg_ms, 4), "launches_timed": len(dom_ms), "timed_on": "the steps right after the timed region (dispatch-attached hipEvents perturb the call stream by ~14 us per call)", "alg_bytes_per_launch": alg_bytes,
                     "whole_call_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if traffic:   # the same launch time against the bytes the kernel really moves (halo planes and rows, outputs)
+            roofline["traffic_frac"] = round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if call_ms:
             roofline["call_median_ms_hipevents"] = round(call_ms[len(call_ms) // 2], 4)
         roofline["cold_first_call_ms"] = round(cold_ms, 3)

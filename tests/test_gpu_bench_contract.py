@@ -43,6 +43,10 @@ def test_default_run_reports_the_other_configs(gpu):
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
     assert d["metric"].startswith("Mvoxels/s on 512^3 fp32 SDF") and d["dtype"] == "f32" and d["steps"] == 3
     assert abs(d["value"] - 512 ** 3 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
+    # the headline workload carries the measured HBM traffic of its dominant kernel and the fraction of the peak that the
+    # kernel reaches on THOSE bytes (>= the fraction on the algorithmic bytes)
+    r = d["roofline"]
+    assert r["traffic"] > r["alg_bytes_per_launch"] and r["frac"] <= r["traffic_frac"] < 1.0
     oc = d["other_configs"]
     assert sorted(oc) == ["c2", "c4_1gpu", "c5"]
     nvox = {"c2": 256 ** 3, "c5": 32 * 256 ** 3, "c4_1gpu": 1024 ** 3}
