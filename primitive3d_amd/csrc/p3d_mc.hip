@@ -740,33 +740,39 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
     const bool valid = (p < d.P) && (y + 1 < d.ry);
     const bool more = c + 1 < d.ncz;
     const u64 cells = valid ? zedge(d, c) : 0ull;
+    // the wave's last unit and whether its row goes on behind it (wave-uniform)
+    const int64_t p63 = tile * kBlock + (int64_t)__builtin_amdgcn_readfirstlane(wave) * 64 + 63;
+    const bool need63 = __builtin_amdgcn_readlane((int)(valid && more), 63) != 0;
     u32 running = 0;  // first wave: triangles of the chunk before the current sub-batch
     for (int64_t xs = x_begin; xs < x_end; xs += PB) {
         u64 Wp[PB + 1], Wq[PB + 1];  // columns (x', y) and (x', y+1) of this unit for x' = xs .. xs+PB
         u32 first = 0, nbs = 0;
+        // first bit of the next chunk of both columns, all planes in one word: the next lane has them (same row).  The
+        // wave's last lane needs them of the unit behind the wave's 64: lane 2i (+1) loads the low dword of that unit's
+        // column in plane xs + i (its row-above column) -- ONE vector load in front of the columns' own, travelling with
+        // them, and a ballot over its bit 0 is the word (as loads of the last lane behind the shuffle below they were a
+        // second memory round trip per wave)
+        u32 nxv;
+        {
+            const bool mine = need63 && lane < 2 * (PB + 1);
+            const int64_t un = mine ? min(xs + (lane >> 1), d.rx - 1) * d.P + p63 + 1 + ((lane & 1) ? d.ncz : 0) : 0;
+            nxv = ((const u32*)bits)[2 * un];   // (always a valid address: no branch)
+            nxv = mine ? nxv & 1u : 0u;
+        }
         static_for<0, PB + 1>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int64_t u = min(xs + i, d.rx - 1) * d.P + p;
             Wp[i] = valid ? bits[u] : 0ull;
             Wq[i] = valid ? bits[u + d.ncz] : 0ull;
         });
-        // first bit of the next chunk of both columns, all planes in one word: the next lane has them (same row);
-        // the wave's last lane loads them (a second memory round trip for that lane; hoisting these loads in front of the
-        // columns made the compiler wait after every pair of them -- nine round trips -- and was dropped)
         static_for<0, PB + 1>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             first |= ((u32)(Wp[i] & 1ull) | ((u32)(Wq[i] & 1ull) << 1)) << (2 * i);
         });
         nbs = (u32)__shfl_down((int)first, 1, 64);
-        if (lane == 63) {
-            nbs = 0;
-            if (valid && more) {
-                static_for<0, PB + 1>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    const int64_t u = min(xs + i, d.rx - 1) * d.P + p;
-                    nbs |= ((u32)(bits[u + 1] & 1ull) | ((u32)(bits[u + d.ncz + 1] & 1ull) << 1)) << (2 * i);
-                });
-            }
+        {
+            const u32 n63 = (u32)__ballot(nxv != 0u);   // bit 2i / 2i+1 = lane 2i / 2i+1: the layout of `first`
+            if (lane == 63) nbs = n63;
         }
         if (!more) nbs = 0;
         // A wave all of whose units are entirely outside (every word 0) or entirely inside (every word all ones)
