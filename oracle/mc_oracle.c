@@ -224,11 +224,21 @@ int p3d_oracle_extract_mt(const float* grid, int64_t rx, int64_t ry, int64_t rz,
     if (rx < 1 || ry < 1 || rz < 1) return -1;
     const int64_t sy = rz, sx = ry * rz;
     const int64_t nvox = rx * ry * rz;
-    int32_t* vgrid = (int32_t*)calloc((size_t)nvox * 3, sizeof(int32_t));
+    /* The dense id grid (the reference's vertex_grids, 12 B per voxel: 1.6 GB at 512^3) is kept between calls and
+     * cleared by all threads: a fresh calloc per extraction spent most of a many-core run in page faults (128 threads
+     * ran only 2x faster than one), which says nothing about the algorithm on the host's cores.  Not thread-safe across
+     * concurrent callers -- the baseline and the tests call it from one thread. */
+    static int32_t* vgrid_cache = NULL;
+    static size_t vgrid_words = 0;
+    if (vgrid_words < (size_t)nvox * 3) {
+        free(vgrid_cache);
+        vgrid_cache = (int32_t*)malloc((size_t)nvox * 3 * sizeof(int32_t));
+        vgrid_words = vgrid_cache ? (size_t)nvox * 3 : 0;
+    }
+    int32_t* vgrid = vgrid_cache;
     int64_t* vfirst = (int64_t*)calloc((size_t)rx + 1, sizeof(int64_t));
     int64_t* ffirst = (int64_t*)calloc((size_t)rx + 1, sizeof(int64_t));
     if (!vgrid || !vfirst || !ffirst) {
-        free(vgrid);
         free(vfirst);
         free(ffirst);
         return -2;
@@ -244,9 +254,10 @@ int p3d_oracle_extract_mt(const float* grid, int64_t rx, int64_t ry, int64_t rz,
 #else
     (void)nthreads;
 #endif
-    /* per-plane counts (count_vertices_faces_kernel restricted to one x) */
+    /* per-plane counts (count_vertices_faces_kernel restricted to one x); the plane's ids are cleared on the way */
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t x = 0; x < rx; ++x) {
+        memset(vgrid + x * sx * 3, 0, (size_t)sx * 3 * sizeof(int32_t));
         int64_t nv = 0, nf = 0;
         for (int64_t y = 0; y < ry; ++y)
             for (int64_t z = 0; z < rz; ++z) {
@@ -313,7 +324,6 @@ int p3d_oracle_extract_mt(const float* grid, int64_t rx, int64_t ry, int64_t rz,
             }
     }
     const int64_t nv_total = vfirst[rx];
-    free(vgrid);
     free(vfirst);
     free(ffirst);
     p3d_oracle_epilogue(rx, ry, rz, lower, upper, verts, nv_total);
