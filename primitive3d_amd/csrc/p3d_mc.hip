@@ -1766,7 +1766,7 @@ void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const 
                   int x_hi,
                     hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
     // tile geometries (32 unit words per wave-plane unless noted): long rows (8 chunks x 3 rows per wave), rows of 3-4
-    // chunks (rz <= 256: 4 chunks x 7 rows -- the 8-chunk tile would be half empty -- or, for a single small grid,
+    // chunks (rz <= 256: 4 chunks x 6 rows -- the 8-chunk tile would be half empty -- or, for a single small grid,
     // 16-unit tiles of 4 chunks x 3 rows), short rows (2 chunks x 15 rows)
     const int rem = (int)(d.ncz % 8);
     if (d.ncz >= 9 && rem >= 1 && rem <= 2 && tuning().split_rows) {
@@ -1786,8 +1786,11 @@ void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const 
     else if (d.ncz >= 3 &&
              // (only when 8-plane slabs of the wider-in-y tile still give the chip enough blocks: a single small grid is
              //  better off with more, half-empty tiles than with 2-plane slabs)
-             ((d.ry + 27) / 28) * (d.stack ? d.nitems : 1) * ((x_hi - x_lo + 7) / 8) >= 1024)
-        launch_fused<T, 4, 7>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+             ((d.ry + 23) / 24) * (d.stack ? d.nitems : 1) * ((x_hi - x_lo + 7) / 8) >= 1024)
+        // (4 x 6 rows, not the 4 x 7 that would fill the 32 unit slots: a wave-plane of 28 units carries ~75 vertices on the
+        //  Perlin stacks -- a full batch of 64 and a nearly empty one --, one of 24 units ~64: 32 x 256^3 fp16 342 -> 328 us,
+        //  fp32 556 -> 535 us)
+        launch_fused<T, 4, 6>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
                               store_rows, x_lo, x_hi, ev0, ev1, st);
     else if (d.ncz >= 3 && tuning().small16)
         // a single small grid: 16-unit tiles (4 chunks x 3 rows + halo row) -- twice the waves of the 8-chunk tile, none

@@ -5,7 +5,8 @@ import torch
 import primitive3d_amd as p3d
 from primitive3d_amd.fields import perlin_grid
 B = int(os.environ.get("B", "32"))
-grids = torch.stack([perlin_grid(256, period=64, seed=s, device="cuda") for s in range(B)]).half()
+grids = torch.stack([perlin_grid(256, period=64, seed=s, device="cuda") for s in range(B)])
+if not os.environ.get("F32"): grids = grids.half()
 for _ in range(2): out = p3d.marching_cubes_batched(grids, 0.0)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(5): out = p3d.marching_cubes_batched(grids, 0.0)
