@@ -489,11 +489,6 @@ struct FaceArgs {
     int xw_shift = 0;                                                           // log2(xw)
 };
 
-#ifndef P3D_WAVE_CELLS
-#define P3D_WAVE_CELLS 256   // (2 KiB of cell lists per block: with 4 KiB the block's LDS allows 5 blocks per CU, with 2 KiB 6)
-#endif
-constexpr int kWaveCells = P3D_WAVE_CELLS;  // active cells a wave expands at a time (its 64 units have up to 4096)
-
 __device__ inline void wave_lds_sync() {  // orders one wave's LDS traffic across its lanes (no block barrier)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
