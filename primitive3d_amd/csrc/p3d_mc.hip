@@ -1075,12 +1075,15 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     uint2 lr[2 * NST];
 #pragma unroll
     for (int q = 0; q < NST; ++q) {
-        lw[4 * q + 0] = bw0[so[q]];
-        lw[4 * q + 1] = bw1[so[q]];
-        lw[4 * q + 2] = bw0[sy[q]];
-        lw[4 * q + 3] = bw1[sy[q]];
-        lr[2 * q + 0] = br0[so[q]];
-        lr[2 * q + 1] = br1[so[q]];
+        // (32-bit BYTE offsets -- a plane has fewer than 2^29 units -- so that the loads take the scalar base + 32-bit
+        //  vector offset form instead of a 64-bit vector address each)
+        const u32 bo = so[q] * 8u, by = sy[q] * 8u;
+        lw[4 * q + 0] = *(const u64*)((const char*)bw0 + bo);
+        lw[4 * q + 1] = *(const u64*)((const char*)bw1 + bo);
+        lw[4 * q + 2] = *(const u64*)((const char*)bw0 + by);
+        lw[4 * q + 3] = *(const u64*)((const char*)bw1 + by);
+        lr[2 * q + 0] = *(const uint2*)((const char*)br0 + bo);
+        lr[2 * q + 1] = *(const uint2*)((const char*)br1 + bo);
     }
     FSTAMP_NOWAIT(1);   // all prologue loads issued
     // (a tile without triangles leaves only in front of the barrier, behind the staging: a branch HERE lets the compiler
