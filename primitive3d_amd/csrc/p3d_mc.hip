@@ -1169,20 +1169,20 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     int32_t* const wfaces = faces + (size_t)wrun0 * 3;   // (wave-uniform base: the stores take a 32-bit offset)
     u32 rel = 0;                                          // faces this wave has written so far (uniform)
 
-    auto colw = [&](int k, int t) -> u64 { return s_w[(k == 1 || k == 2) ? 1 : 0][t + (k >= 2 ? hoff : 0)]; };
-    // per unit (lane = unit of this wave): active cells
+    // per unit (lane = unit of this wave): active cells.  A cell is inactive when its eight corners agree, i.e. when bits z
+    // and z+1 of all four columns are 0 (of their OR) or all 1 (of their AND): two words and ONE shifted copy of each
+    // instead of four columns with a shifted copy each.  The unit's own columns are still in the registers of the prologue
+    // (first staging pass: lane = unit); bit z+1 at z = 63 is bit 0 of the next chunk's columns, read from the staged words.
     u64 act_all = 0;
     {
-        u64 orr = 0, andd = ~0ull;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const u64 Wk = valid ? colw(k, tid) : 0ull;
-            const u64 nb = (valid && more) ? (colw(k, tid + 1) & 1ull) : 0ull;
-            const u64 S = (Wk >> 1) | (nb << 63);
-            orr |= Wk | S;
-            andd &= Wk & S;
-        }
-        if (valid) act_all = orr & ~andd & zedge(d, c);
+        const u64 Xo = st_w0[0] | st_w1[0] | st_y0[0] | st_y1[0], Na = st_w0[0] & st_w1[0] & st_y0[0] & st_y1[0];
+        const u32* const L0 = (const u32*)s_w[0];
+        const u32* const L1 = (const u32*)s_w[1];
+        const u32 n0 = L0[2 * (tid + 1)], n1 = L1[2 * (tid + 1)], n3 = L0[2 * (tid + 1 + hoff)], n2 = L1[2 * (tid + 1 + hoff)];
+        const u64 xn = (valid && more) ? (u64)((n0 | n1 | n2 | n3) & 1u) : 0ull;
+        const u64 nn = (valid && more) ? (u64)((n0 & n1 & n2 & n3) & 1u) : 0ull;
+        const u64 Sx = (Xo >> 1) | (xn << 63), Sn = (Na >> 1) | (nn << 63);
+        if (valid) act_all = (Xo | Sx) & ~(Na & Sn) & zedge(d, c);
     }
     // phase B (lane = unit): the wave's active cells are numbered unit by unit, ascending z (no list is built: a list
     // needs one loop trip per active cell of the wave's FULLEST unit -- tens of trips where the surface runs along z --
