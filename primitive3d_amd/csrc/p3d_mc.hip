@@ -1067,10 +1067,14 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
 #pragma unroll
     for (int k = 0; k < 4; ++k) cp4[k] = a.chunk_sum + min((u32)tid + (u32)k * kBlock, mychunk32);
     // ---- the loads: one batch ----
-    const u32 misc = *mp;
+    // (relaxed workgroup-scope ATOMIC loads: the same plain instructions, but the compiler may not sink them below the
+    //  empty-tile exit that follows -- ordinary loads it moved behind that branch, i.e. behind the wait for the first one)
+    auto ld32 = [](const void* p) -> u32 { return __hip_atomic_load((const u32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto ld64 = [](const void* p) -> u64 { return __hip_atomic_load((const u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    const u32 misc = ld32(mp);
     u32 part[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) part[k] = *cp4[k];
+    for (int k = 0; k < 4; ++k) part[k] = ld32(cp4[k]);
     u64 lw[4 * NST];
     uint2 lr[2 * NST];
 #pragma unroll
@@ -1078,17 +1082,19 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
         // (32-bit BYTE offsets -- a plane has fewer than 2^29 units -- so that the loads take the scalar base + 32-bit
         //  vector offset form instead of a 64-bit vector address each)
         const u32 bo = so[q] * 8u, by = sy[q] * 8u;
-        lw[4 * q + 0] = *(const u64*)((const char*)bw0 + bo);
-        lw[4 * q + 1] = *(const u64*)((const char*)bw1 + bo);
-        lw[4 * q + 2] = *(const u64*)((const char*)bw0 + by);
-        lw[4 * q + 3] = *(const u64*)((const char*)bw1 + by);
-        lr[2 * q + 0] = *(const uint2*)((const char*)br0 + bo);
-        lr[2 * q + 1] = *(const uint2*)((const char*)br1 + bo);
+        lw[4 * q + 0] = ld64((const char*)bw0 + bo);
+        lw[4 * q + 1] = ld64((const char*)bw1 + bo);
+        lw[4 * q + 2] = ld64((const char*)bw0 + by);
+        lw[4 * q + 3] = ld64((const char*)bw1 + by);
+        const u64 r0 = ld64((const char*)br0 + bo), r1 = ld64((const char*)br1 + bo);
+        lr[2 * q + 0] = make_uint2((u32)r0, (u32)(r0 >> 32));
+        lr[2 * q + 1] = make_uint2((u32)r1, (u32)(r1 >> 32));
     }
     FSTAMP_NOWAIT(1);   // all prologue loads issued
-    // (a tile without triangles leaves only in front of the barrier, behind the staging: a branch HERE lets the compiler
-    //  sink every load that follows in program order below it, i.e. behind the wait for this first one)
+    // a tile without triangles leaves here, in front of the staging (sparse fields -- an object's SDF in a box -- are mostly
+    // such tiles)
     const u32 my_tris = (u32)__builtin_amdgcn_readlane((int)misc, 32);
+    if (my_tris == 0u) return;   // (block-uniform)
     FSTAMP(2);          // ... and returned
     u64 st_w0[NST], st_w1[NST], st_y0[NST], st_y1[NST];
     uint2 st_r0[NST], st_r1[NST];
@@ -1155,7 +1161,6 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
         if (lane == 0) s_tmp[wave] = cs;
     }
     FSTAMP(3);          // staged (LDS writes done)
-    if (my_tris == 0u) return;   // (block-uniform)
     __syncthreads();  // the only block barrier: staging done (no store is in flight yet)
     FSTAMP_NOWAIT(4);   // barrier passed
 #if P3D_FACES_ABL == 1
