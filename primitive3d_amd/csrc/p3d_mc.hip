@@ -1728,8 +1728,10 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
         const int64_t blocks_at_8 = per_slab * ((nplanes + 7) / 8);
         if (blocks_at_8 >= 1024) xt = 8;
         else {
-            const int64_t slabs_for_1024 = (1024 + per_slab - 1) / per_slab;
-            xt = (int)std::max<int64_t>(1, std::min<int64_t>(8, (nplanes + slabs_for_1024 - 1) / slabs_for_1024));
+            // (about 1400 blocks: a block and a half per slot of the chip -- 256^3: 4 planes per block 25.9 us, 6 planes
+            //  27.4, 8 planes 28.9 on the round-3 kernel)
+            const int64_t slabs_for_fill = (1400 + per_slab - 1) / per_slab;
+            xt = (int)std::max<int64_t>(1, std::min<int64_t>(8, (nplanes + slabs_for_fill - 1) / slabs_for_fill));
         }
     }
     if (tn.fused_xt >= 0) xt = tn.fused_xt;
