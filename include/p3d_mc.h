@@ -196,9 +196,17 @@ const char* p3d_mc_profile_stage_name(int stage);
 /* Developer / test hook (no reference counterpart).  The launch-shape knobs of the developer sweeps and the two test
  * hooks (P3D_FUSED_BLOCKS, P3D_FUSED_XT, P3D_FUSED_XT_TAIL, P3D_FUSED_TAIL_DIV, P3D_FUSED_SPLIT_ROWS,
  * P3D_FUSED_SMALL16, P3D_COMPACT_BLOCKS, P3D_COMPACT_EARLY, P3D_STACK_NPARTS, P3D_STACK_EARLY, P3D_TEST_ID_LIMIT,
- * P3D_TEST_INDEX_LIMIT, P3D_NO_CHUNK_PRE) are read from the environment ONCE, at
+ * P3D_TEST_INDEX_LIMIT, P3D_NO_CHUNK_PRE, P3D_FUSED_DYN, P3D_FUSED_DYN_MIN_PLANES) are read from the environment ONCE, at
  * the first call; this re-reads them.  Not to be called while another thread is inside the library. */
 int p3d_mc_reload_tuning(void);
+
+/* Counters of what the library has launched since it was loaded (no reference counterpart; tests and the bench read them
+ * to see which path a call took -- nothing in the data path depends on them):
+ *   out[0] streaming launches with fixed x-slabs        out[1] streaming launches with the dynamic plane hand-out
+ *   out[2] streaming passes of p3d_mc_extract_fused[_batched] that wrote or counted a whole grid / stack (part 0 or 2, 3)
+ *   out[3] calls of the counting / gather pair p3d_mc_count + p3d_mc_emit
+ * Writes min(n, 4) values, returns how many. */
+int p3d_mc_debug_counters(int64_t* out, int n);
 
 const char* p3d_last_error(void);
 int p3d_mc_abi_version(void);

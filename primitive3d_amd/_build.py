@@ -40,6 +40,11 @@ def _write_stamp(out: Path, deps, extra=""):
     out.with_name(out.name + ".stamp").write_text(_digest(deps, extra) + "\n")
 
 
+# k_fused's plane claims are `if (lane == 0) old = atomic add`, consumed one plane later: LLVM's atomic optimizer would
+# rewrite that into a wave reduction that reads the result (and waits for it) right behind the atomic
+CAPI_EXTRA_FLAGS = ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
+
+
 def capi_path() -> Path:
     override = os.environ.get("P3D_CAPI_LIB")  # dev: try an alternative build of the C-ABI library
     return Path(override) if override else PKG / "libp3dmc.so"
@@ -52,15 +57,15 @@ def pybind_path() -> Path:
 def build_capi(force: bool = False, verbose: bool = False) -> Path:
     out = capi_path()
     deps = [CSRC / "p3d_mc.hip", *sorted(CSRC.glob("*.inc")), *sorted(CSRC.glob("*.h")), ROOT / "include" / "p3d_mc.h"]
-    if force or _stale(out, deps):
+    if force or _stale(out, deps, " ".join(CAPI_EXTRA_FLAGS)):
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
                # the reference epilogue is mul-then-add, never an FMA (marching_cubes.cu:298)
-               "-ffp-contract=off", "-Wall", "-Wextra", 
+               "-ffp-contract=off", "-Wall", "-Wextra", *CAPI_EXTRA_FLAGS,
                str(CSRC / "p3d_mc.hip"), "-o", str(out)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
-        _write_stamp(out, deps)
+        _write_stamp(out, deps, " ".join(CAPI_EXTRA_FLAGS))
     return out
 
 

@@ -15,7 +15,8 @@ P3D_ERANGE = -2
 SYMBOLS = ("p3d_mc_abi_version", "p3d_last_error", "p3d_mc_workspace_bytes", "p3d_mc_count",
            "p3d_mc_read_counts", "p3d_mc_emit", "p3d_mc_plane_records", "p3d_mc_export_plane_records", "p3d_mc_profile_enable",
            "p3d_mc_profile_read", "p3d_mc_profile_stage_name", "p3d_mc_extract_fused", "p3d_mc_debug_layout",
-           "p3d_mc_workspace_bytes_batched", "p3d_mc_extract_fused_batched", "p3d_mc_reload_tuning")
+           "p3d_mc_workspace_bytes_batched", "p3d_mc_extract_fused_batched", "p3d_mc_reload_tuning",
+           "p3d_mc_debug_counters")
 
 
 class Slab(ctypes.Structure):
@@ -59,6 +60,7 @@ def lib():
                                                    c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]
         L.p3d_mc_debug_layout.argtypes = [c_int64, c_int64, c_int64, POINTER(c_size_t), POINTER(c_size_t),
                                           POINTER(c_int64), POINTER(c_int32)]
+        L.p3d_mc_debug_counters.argtypes = [POINTER(c_int64), c_int]
         L.p3d_mc_profile_enable.argtypes = [c_int]
         L.p3d_mc_profile_read.argtypes = [POINTER(c_float), c_int]
         L.p3d_mc_profile_stage_name.argtypes = [c_int]
@@ -140,6 +142,14 @@ def emit(grid, thresh, lower, upper, ws, vertices, faces, vertex_keys=None, slab
                                  c_void_p(faces.data_ptr()) if capf else None, capf,
                                  c_void_p(vertex_keys.data_ptr()) if vertex_keys is not None and capv else None,
                                  _stream_ptr(grid)), "p3d_mc_emit")
+
+
+def debug_counters():
+    """p3d_mc_debug_counters: what the library has launched since it was loaded."""
+    out = (c_int64 * 4)()
+    n = lib().p3d_mc_debug_counters(out, 4)
+    assert n == 4, n
+    return {"fixed_slab_launches": out[0], "dynamic_launches": out[1], "streaming_passes": out[2], "count_emit_calls": out[3]}
 
 
 def reload_tuning():

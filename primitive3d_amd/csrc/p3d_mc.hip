@@ -29,6 +29,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <memory>
 #include <mutex>
@@ -38,6 +39,7 @@
 #include "../../include/p3d_mc.h"
 #include "fastdiv.h"
 #include "half_round.h"
+#include "range_sched.h"
 #include "tri_table_packed.inc"
 
 namespace {
@@ -162,8 +164,9 @@ Ws make_ws(const Dims& d) {
     o = align_up(o + (size_t)(w.nb_f + 1) * 4 * 4, 256);
     w.tile_tris = o;   // triangles of every face tile (an empty tile's block returns at once)
     o = align_up(o + (size_t)(w.nb_f + 1) * 4, 256);
-    w.cur = o;         // a stack of items keeps one block of 32 vertex cursors per item here
-    if (d.stack) o = align_up(o + (size_t)d.nitems * 32 * 16 * 8, 256);
+    w.cur = o;         // a stack of items keeps one block of 32 vertex cursors per item here, and behind them the plane
+                       // hand-out table of its streaming launch (range_sched.h)
+    if (d.stack) o = align_up(o + ((size_t)d.nitems * 32 * 16 + kRsTableWords) * 8, 256);
     w.total = o;
     return w;
 }
@@ -1426,17 +1429,20 @@ int env_int(const char* name, int dflt) {
 // first call (no getenv in the per-call host path); -1 = "use the built-in rule".
 struct Tuning {
     int fused_blocks, fused_xt, fused_xt_tail, fused_tail_div, split_rows, small16, compact_blocks, compact_early,
-        test_id_limit, no_chunk_pre, test_index_limit, stack_nparts, stack_early;
+        test_id_limit, no_chunk_pre, test_index_limit, stack_nparts, stack_early, fused_dyn, dyn_min_planes;
 };
 Tuning read_tuning() {
     return Tuning{env_int("P3D_FUSED_BLOCKS", 2048), env_int("P3D_FUSED_XT", -1), env_int("P3D_FUSED_XT_TAIL", -1),
                   env_int("P3D_FUSED_TAIL_DIV", 4), env_int("P3D_FUSED_SPLIT_ROWS", 1), env_int("P3D_FUSED_SMALL16", 1),
                   env_int("P3D_COMPACT_BLOCKS", 256), env_int("P3D_COMPACT_EARLY", 3),
                   env_int("P3D_TEST_ID_LIMIT", 1 << 26), env_int("P3D_NO_CHUNK_PRE", 0),
-                  env_int("P3D_TEST_INDEX_LIMIT", 0x7fffffff), env_int("P3D_STACK_NPARTS", -1), env_int("P3D_STACK_EARLY", -1)};
+                  env_int("P3D_TEST_INDEX_LIMIT", 0x7fffffff), env_int("P3D_STACK_NPARTS", -1), env_int("P3D_STACK_EARLY", -1),
+                  env_int("P3D_FUSED_DYN", 1), env_int("P3D_FUSED_DYN_MIN_PLANES", 64)};
 }
 Tuning g_tuning;
 std::once_flag g_tuning_once;
+// what has been launched so far (p3d_mc_debug_counters): fixed-slab / dynamic streaming launches, streaming passes, count+emit calls
+std::atomic<int64_t> g_counters[4];
 const Tuning& tuning() {
     std::call_once(g_tuning_once, [] { g_tuning = read_tuning(); });
     return g_tuning;
@@ -1449,6 +1455,7 @@ const Tuning& tuning() {
 // kCursorRing - 1 calls earlier on the same stream (stream order makes that safe).  A slab streamed in two parts
 // keeps its block for the second part.
 constexpr int kCursorRing = 4;
+constexpr int kRingSlotWords = kCursorBlockWords + kRsTableWords;   // 32 cursors, then the plane hand-out table (range_sched.h)
 struct CursorRing {
     int dev = -1;
     hipStream_t stream = nullptr;
@@ -1481,7 +1488,7 @@ int cursor_block_for(hipStream_t st, RingLease* lease, u64** block, u64** zero_n
             std::unique_ptr<CursorRing> n(new CursorRing);
             n->dev = dev;
             n->stream = st;
-            const size_t bytes = (size_t)kCursorRing * kCursorBlockWords * sizeof(u64);
+            const size_t bytes = (size_t)kCursorRing * kRingSlotWords * sizeof(u64);
             HIP_TRY(hipMalloc((void**)&n->base, bytes));
             HIP_TRY(hipMemsetAsync(n->base, 0, bytes, st));
             n->cur = kCursorRing - 1;
@@ -1491,8 +1498,8 @@ int cursor_block_for(hipStream_t st, RingLease* lease, u64** block, u64** zero_n
     }
     lease->lock = std::unique_lock<std::mutex>(r->mu);
     r->cur = (r->cur + 1) % kCursorRing;
-    *block = r->base + (size_t)r->cur * kCursorBlockWords;
-    *zero_next = r->base + (size_t)((r->cur + 1) % kCursorRing) * kCursorBlockWords;
+    *block = r->base + (size_t)r->cur * kRingSlotWords;
+    *zero_next = r->base + (size_t)((r->cur + 1) % kCursorRing) * kRingSlotWords;
     return P3D_OK;
 }
 
@@ -1631,6 +1638,7 @@ int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3
     u32 *csum = (u32*)(ws + w.chunk_sum), *woff = (u32*)(ws + w.wave_off);
 
     HIP_TRY(hipMemsetAsync(hdr + H_FLAGS, 0, 2 * sizeof(u64), st));  // no overflow, dense ids
+    g_counters[3].fetch_add(1, std::memory_order_relaxed);
     u64 seq = 0;
     u64* mb = mailbox_open(ws, &seq);
     // classify: 64 units (16 KiB of fp32) per wave iteration; cap the grid and stride the rest
@@ -1700,11 +1708,30 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
 }
 
 
+// blocks of the DYN streaming kernel the device holds at once (per variant and device; 0 = not asked yet)
 template <typename T, int NC, int RY>
+int fused_resident_blocks() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cached[dev] == 0) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fused<T, NC, RY, true>, kFusedBlock, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            cached[dev] = -1;
+        } else {
+            cached[dev] = std::max(1, per_cu * cus);
+        }
+    }
+    return cached[dev] > 0 ? cached[dev] : 0;
+}
+
+template <typename T, int NC, int RY, bool kHasDyn>
 void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xform& t, int64_t x_origin, u64* bits,
                   uint2* rec, u64* cursors, u64* zero_next, float* scratch, u32 region_rows, u32 store_rows, int x_lo,
                   int x_hi,
-                  hipEvent_t ev0, hipEvent_t ev1, hipStream_t st, int cz_base = 0, int cz_count = -1) {
+                  hipEvent_t ev0, hipEvent_t ev1, hipStream_t st, u64* rs_table, int cz_base = 0, int cz_count = -1) {
     FusedGeom g;
     g.x_lo = x_lo;
     g.x_hi = x_hi;
@@ -1719,10 +1746,43 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
     // planes per block: enough blocks to fill the chip a few times over, but >= 8 planes (x-halo overhead 1/XT)
     // unless the grid is so small that 8-plane blocks would leave most CUs idle (then latency wins over the halo)
     const int64_t per_slab = (int64_t)g.nzt * g.nyt * (stack ? d.nitems : 1);
+    const Tuning& tn = tuning();
+    const u32 thresh16 = half_round_down(thresh);
+    // ---- DYN: persistent blocks, planes handed out dynamically (range_sched.h), when the caller has a (zeroed) table for
+    // them, the numbers fit the table's fields and the chip's worth of blocks gets LONG ranges (>= 64 planes each: a single
+    // grid of 1024^3 or more).  Measured (profiles/r04/dyn_ranges.txt): the hand-out cuts the x-halo re-reads (512^3:
+    // 689 -> 600 MB read) but a block that runs dry pays ~8 us to find, take and prime a stolen range, and the end of the
+    // launch is a few in-hand planes per block either way; at 512^3 (21 planes per range) the kernel takes what the fixed
+    // slabs take (116-120 vs 117 us), stacks of small grids and mid-size grids lose 5-14 %, 1024^3 gains 8 %.
+    // P3D_FUSED_DYN: 0 never, 1 by this rule (default), 2 whenever it is possible (>= 2 planes per range; dev sweeps).
+    if constexpr (kHasDyn) {
+        if (rs_table && tn.fused_dyn > 0) {
+            int nb = std::min(fused_resident_blocks<T, NC, RY>(), kRsMaxBlocks);
+            if (tn.fused_blocks > 0 && tn.fused_blocks < nb && tn.fused_dyn > 2) nb = tn.fused_blocks;   // (dev sweeps: P3D_FUSED_DYN=3)
+            nb -= nb % 8;
+            if (nb >= 8 && per_slab <= nb && per_slab < (1 << kRsColBits) && nplanes < (1ll << kRsBits) &&
+                per_slab * nplanes >= (int64_t)nb * (tn.fused_dyn > 1 ? 2 : std::max(2, tn.dyn_min_planes)) && (!stack || tn.fused_dyn > 1)) {
+                g.XT = g.XT_tail = 1;
+                g.n_big = g.nxt = 0;
+                if (stack) g.nxt_item = 1;   // (marks a stack: the item is the tile column's third coordinate)
+                const RsGeom rs = rs_make_geom((u32)nb, (u32)per_slab, (u32)nplanes);
+                g_counters[1].fetch_add(1, std::memory_order_relaxed);
+                if (ev0 || ev1)
+                    hipExtLaunchKernelGGL((k_fused<T, NC, RY, true>), dim3((u32)nb), dim3(kFusedBlock), 0, st, ev0, ev1, 0, grid,
+                                          thresh, thresh16, d, g, halo, t, x_origin, bits, rec, cursors, zero_next, scratch,
+                                          region_rows, store_rows, rs, rs_table);
+                else
+                    hipLaunchKernelGGL((k_fused<T, NC, RY, true>), dim3((u32)nb), dim3(kFusedBlock), 0, st, grid, thresh,
+                                       thresh16, d, g, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                                       store_rows, rs, rs_table);
+                return;
+            }
+        }
+    }
+    // ---- fixed x-slabs
     // (measured, tools/dev/xt_sweep*.sh / blocks_sweep.sh: about 2000 blocks and at most 16 planes per block -- 12 planes
     //  at 512^3 (120 us vs 124 with 8), 16 at 1024^3 (976 us vs 1140 with the 43 an uncapped rule gave))
-    const Tuning& tn = tuning();
-    int64_t want_slabs = (tn.fused_blocks + per_slab - 1) / per_slab;
+    int64_t want_slabs = std::max<int64_t>(1, (std::max(1, tn.fused_blocks) + per_slab - 1) / per_slab);
     int xt = (int)std::min<int64_t>(16, (nplanes + want_slabs - 1) / want_slabs);
     if (xt < 8) {
         const int64_t blocks_at_8 = per_slab * ((nplanes + 7) / 8);
@@ -1754,40 +1814,43 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
         g.XT_tail = xt;
     }
     const int64_t nblocks = per_slab * g.nxt;
-    const u32 thresh16 = half_round_down(thresh);
+    const RsGeom rs0 = rs_make_geom(1, 1, 1);
+    g_counters[0].fetch_add(1, std::memory_order_relaxed);
     // (the timing events, if any, ride on the dispatch packet itself: no extra barrier packets around the kernel)
     if (ev0 || ev1)   // (rows split over two launches: the first carries the start event, the second the stop event)
-        hipExtLaunchKernelGGL((k_fused<T, NC, RY>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, ev0, ev1, 0, grid, thresh,
+        hipExtLaunchKernelGGL((k_fused<T, NC, RY, false>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, ev0, ev1, 0, grid, thresh,
                               thresh16, d, g, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                              store_rows);
+                              store_rows, rs0, (u64*)nullptr);
     else
-        hipLaunchKernelGGL((k_fused<T, NC, RY>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, grid, thresh, thresh16, d, g,
-                           halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows, store_rows);
+        hipLaunchKernelGGL((k_fused<T, NC, RY, false>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, grid, thresh, thresh16, d, g,
+                           halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows, store_rows, rs0,
+                           (u64*)nullptr);
 }
 
 template <typename T>
 void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xform& t, int64_t x_origin, u64* bits,
                     uint2* rec, u64* cursors, u64* zero_next, float* scratch, u32 region_rows, u32 store_rows, int x_lo,
                   int x_hi,
-                    hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
+                    hipEvent_t ev0, hipEvent_t ev1, hipStream_t st, u64* rs_table) {
     // tile geometries (32 unit words per wave-plane unless noted): long rows (8 chunks x 3 rows per wave), rows of 3-4
     // chunks (rz <= 256: 4 chunks x 6 rows -- the 8-chunk tile would be half empty -- or, for a single small grid,
-    // 16-unit tiles of 4 chunks x 3 rows), short rows (2 chunks x 15 rows)
+    // 16-unit tiles of 4 chunks x 3 rows), short rows (2 chunks x 15 rows).  The plane hand-out table (DYN) serves ONE
+    // launch: rows split over two launches keep their fixed slabs.
     const int rem = (int)(d.ncz % 8);
     if (d.ncz >= 9 && rem >= 1 && rem <= 2 && tuning().split_rows) {
         // rows of 8k + 1..2 chunks (rz = 513, 517, 600, 1025: grids of 2^n + 1 samples are common): the 8-chunk tiles take
         // the first 8k chunks, a second launch with the 2-chunk tile the rest -- a last 8-chunk tile would be 1/8 or 1/4
         // full (513 x 511 x 517: 169 -> 155 us; with 3..4 chunks left over the split measured no gain)
         const int full = (int)d.ncz - rem;
-        launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                              store_rows, x_lo, x_hi, ev0, nullptr, st, 0, full);
-        launch_fused<T, 2, 15>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                               store_rows, x_lo, x_hi, nullptr, ev1, st, full, rem);
+        launch_fused<T, 8, 3, false>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                                     store_rows, x_lo, x_hi, ev0, nullptr, st, nullptr, 0, full);
+        launch_fused<T, 2, 15, false>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                                      store_rows, x_lo, x_hi, nullptr, ev1, st, nullptr, full, rem);
         return;
     }
     if (d.ncz >= 5)
-        launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                              store_rows, x_lo, x_hi, ev0, ev1, st);
+        launch_fused<T, 8, 3, true>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                                    store_rows, x_lo, x_hi, ev0, ev1, st, rs_table);
     else if (d.ncz >= 3 &&
              // (only when 8-plane slabs of the wider-in-y tile still give the chip enough blocks: a single small grid is
              //  better off with more, half-empty tiles than with 2-plane slabs)
@@ -1795,19 +1858,19 @@ void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const 
         // (4 x 6 rows, not the 4 x 7 that would fill the 32 unit slots: a wave-plane of 28 units carries ~75 vertices on the
         //  Perlin stacks -- a full batch of 64 and a nearly empty one --, one of 24 units ~64: 32 x 256^3 fp16 342 -> 328 us,
         //  fp32 556 -> 535 us)
-        launch_fused<T, 4, 6>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                              store_rows, x_lo, x_hi, ev0, ev1, st);
+        launch_fused<T, 4, 6, true>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                                    store_rows, x_lo, x_hi, ev0, ev1, st, rs_table);
     else if (d.ncz >= 3 && tuning().small16)
         // a single small grid: 16-unit tiles (4 chunks x 3 rows + halo row) -- twice the waves of the 8-chunk tile, none
         // of them half empty
-        launch_fused<T, 4, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                              store_rows, x_lo, x_hi, ev0, ev1, st);
+        launch_fused<T, 4, 3, false>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                                     store_rows, x_lo, x_hi, ev0, ev1, st, nullptr);
     else if (d.ncz >= 3)
-        launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                              store_rows, x_lo, x_hi, ev0, ev1, st);
+        launch_fused<T, 8, 3, true>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                                    store_rows, x_lo, x_hi, ev0, ev1, st, rs_table);
     else
-        launch_fused<T, 2, 15>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                               store_rows, x_lo, x_hi, ev0, ev1, st);
+        launch_fused<T, 2, 15, false>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                                      store_rows, x_lo, x_hi, ev0, ev1, st, nullptr);
 }
 
 Xform make_xform(const Dims& d, const float lower[3], const float upper[3], const int64_t full_res[3]) {
@@ -1864,13 +1927,17 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
                                (int64_t)kCursorBlockWords);
     }
     if (part < 4) {
+        if (part != 1) g_counters[2].fetch_add(1, std::memory_order_relaxed);
         const int stage = part == 1 ? ST_FUSED_INTERIOR : ST_FUSED;
         const bool timed = g_prof_mode != 0;
         if (timed) g_ev_used[stage] = true;
         if (new_block && part != 1) g_ev_used[ST_FUSED_INTERIOR] = false;
         const int64_t xo = slab ? slab->x_origin : 0;
+        // (the plane hand-out table of a whole-grid call: behind the cursors in the call's ring slot, cleared with them by
+        //  the previous call; an extraction in several parts keeps the fixed x-slabs)
         dispatch_fused<T>(grid, d, thresh, halo, t, xo, bits, rec, cursors, zero_next, scratch, region_rows, store_rows, x_lo, x_hi,
-                          timed ? g_ev[stage][0] : nullptr, timed ? g_ev[stage][1] : nullptr, st);
+                          timed ? g_ev[stage][0] : nullptr, timed ? g_ev[stage][1] : nullptr, st,
+                          part == 0 ? cursors + kCursorBlockWords : nullptr);
     }
     if (part == 3)
         hipLaunchKernelGGL(k_early_header, dim3(1), dim3(64), 0, st, hdr, cursors, scratch ? store_rows : region_rows,
@@ -1934,7 +2001,7 @@ int fused_stack_impl(const T* grids, const Dims& d, const Ws& w, float thresh, c
     u32* cpre = (w.nchunks > kPreMinChunks && !tuning().no_chunk_pre) ? (u32*)(ws + w.chunk_pre) : nullptr;   // (see fused_impl)
     // (an ordinary kernel, not hipMemsetAsync: the runtime's fill path left the GPU idle for 11 us before it ran)
     {
-        const int64_t nwords = (int64_t)d.nitems * kCursorBlockWords;
+        const int64_t nwords = (int64_t)d.nitems * kCursorBlockWords + kRsTableWords;   // (+ the plane hand-out table)
         hipLaunchKernelGGL(k_zero_words, dim3((u32)((nwords + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, cursors, nwords);
     }
     const u32 region_rows = 1u << 26;
@@ -1942,10 +2009,12 @@ int fused_stack_impl(const T* grids, const Dims& d, const Ws& w, float thresh, c
     const u32 store_rows =
         scratch ? (u32)std::min<int64_t>(scratch_rows / ((int64_t)kRegions * d.nitems), (int64_t)region_rows) : 0u;
     const bool timed = g_prof_mode != 0;
+    g_counters[2].fetch_add(1, std::memory_order_relaxed);
     if (timed) g_ev_used[ST_FUSED] = true;
     g_ev_used[ST_FUSED_INTERIOR] = false;
     dispatch_fused<T>(grids, d, thresh, 0, t, 0, bits, rec, cursors, nullptr, scratch, region_rows, store_rows, 0, (int)d.rx,
-                      timed ? g_ev[ST_FUSED][0] : nullptr, timed ? g_ev[ST_FUSED][1] : nullptr, st);
+                      timed ? g_ev[ST_FUSED][0] : nullptr, timed ? g_ev[ST_FUSED][1] : nullptr, st,
+                      cursors + (size_t)d.nitems * kCursorBlockWords);
     u64 seq = 0;
     u64* mb = mailbox_open(ws, &seq);
     const bool copy = scratch && capv > 0;
@@ -2130,10 +2199,25 @@ int p3d_mc_debug_face_stamps(void* buf) {   // dev build only: where k_faces lea
 }
 #endif
 
+#if P3D_RS_STATS
+int p3d_mc_debug_rs_stats(void* buf) {   // dev build only: where the DYN streaming blocks leave their life stamps
+    u64* p = (u64*)buf;
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_rs_stats), &p, sizeof(p)));
+    return P3D_OK;
+}
+#endif
+
 int p3d_mc_reload_tuning(void) {   // dev / test hook: re-read the P3D_* knobs (not for use beside running calls)
     (void)tuning();
     g_tuning = read_tuning();
     return P3D_OK;
+}
+
+int p3d_mc_debug_counters(int64_t* out, int n) {
+    if (!out || n < 0) return fail(P3D_EINVAL, "null pointer%s");
+    const int m = std::min(n, 4);
+    for (int i = 0; i < m; ++i) out[i] = g_counters[i].load(std::memory_order_relaxed);
+    return m;
 }
 
 int p3d_mc_profile_enable(int mode) {

@@ -21,7 +21,8 @@ __global__ void __launch_bounds__(256) k(u64* table, RsGeom g, u32* counts, u32*
     while (have) {
         if (s.claimed > s.xb) {
             for (u32 x = s.xb;; ++x) {
-                const bool own = leader ? rs_leader_own_next(s, x, table + me, s_rs) : rs_sibling_own_next(s, x, s_rs);
+                const bool own = leader ? rs_leader_own_next(s, x, s_rs) : rs_sibling_own_next(s, x, s_rs);
+                if (rs_wants_claim(s, leader)) rs_issue_claim(s, table + (size_t)me * kRsStride);   // (k_fused: inside its plane work, in front of the plane prefetch)
                 if (lane == 0) atomicAdd(&counts[((size_t)s.col * g.nplanes + x) * 4 + wave], 1u);
                 u32 h = (s.col * 2654435761u) ^ (x * 40503u) ^ (wave * 977u);
                 h ^= h >> 13;
@@ -43,8 +44,8 @@ int main() {
         const RsGeom g = rs_make_geom(nb, ncol, npl);
         u64* table; u32 *counts, *steals;
         const size_t n = (size_t)ncol * npl * 4;
-        (void)hipMalloc(&table, nb * 8); (void)hipMalloc(&counts, n * 4); (void)hipMalloc(&steals, 4);
-        (void)hipMemset(table, 0, nb * 8); (void)hipMemset(counts, 0, n * 4); (void)hipMemset(steals, 0, 4);
+        (void)hipMalloc(&table, (size_t)nb * 8 * kRsStride); (void)hipMalloc(&counts, n * 4); (void)hipMalloc(&steals, 4);
+        (void)hipMemset(table, 0, (size_t)nb * 8 * kRsStride); (void)hipMemset(counts, 0, n * 4); (void)hipMemset(steals, 0, 4);
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipEventRecord(e0);
         k<<<nb, 256>>>(table, g, counts, steals, c[3]);
