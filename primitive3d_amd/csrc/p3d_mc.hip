@@ -1437,7 +1437,7 @@ Tuning read_tuning() {
                   env_int("P3D_COMPACT_BLOCKS", 256), env_int("P3D_COMPACT_EARLY", 3),
                   env_int("P3D_TEST_ID_LIMIT", 1 << 26), env_int("P3D_NO_CHUNK_PRE", 0),
                   env_int("P3D_TEST_INDEX_LIMIT", 0x7fffffff), env_int("P3D_STACK_NPARTS", -1), env_int("P3D_STACK_EARLY", -1),
-                  env_int("P3D_FUSED_DYN", 1), env_int("P3D_FUSED_DYN_MIN_PLANES", 64)};
+                  env_int("P3D_FUSED_DYN", 0), env_int("P3D_FUSED_DYN_MIN_PLANES", 64)};
 }
 Tuning g_tuning;
 std::once_flag g_tuning_once;
@@ -1748,13 +1748,13 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
     const int64_t per_slab = (int64_t)g.nzt * g.nyt * (stack ? d.nitems : 1);
     const Tuning& tn = tuning();
     const u32 thresh16 = half_round_down(thresh);
-    // ---- DYN: persistent blocks, planes handed out dynamically (range_sched.h), when the caller has a (zeroed) table for
-    // them, the numbers fit the table's fields and the chip's worth of blocks gets LONG ranges (>= 64 planes each: a single
-    // grid of 1024^3 or more).  Measured (profiles/r04/dyn_ranges.txt): the hand-out cuts the x-halo re-reads (512^3:
-    // 689 -> 600 MB read) but a block that runs dry pays ~8 us to find, take and prime a stolen range, and the end of the
-    // launch is a few in-hand planes per block either way; at 512^3 (21 planes per range) the kernel takes what the fixed
-    // slabs take (116-120 vs 117 us), stacks of small grids and mid-size grids lose 5-14 %, 1024^3 gains 8 %.
-    // P3D_FUSED_DYN: 0 never, 1 by this rule (default), 2 whenever it is possible (>= 2 planes per range; dev sweeps).
+    // ---- DYN: persistent blocks, planes handed out dynamically (range_sched.h) -- OFF by default.  Measured
+    // (profiles/r04/dyn_ranges.txt): the hand-out cuts the x-halo re-reads (512^3: 689 -> 600 MB read per launch) but not the
+    // time: a block that runs dry pays ~8 us to find, take and prime a stolen range, and the end of the launch is a few
+    // in-hand planes per block either way.  512^3: 114-122 us against 116-117 with the fixed slabs; 1024^3: -8 % on one box,
+    // +5 % on another; stacks of small grids and mid-size grids lose 5-14 %.
+    // P3D_FUSED_DYN: 0 never (default), 1 single grids whose blocks get ranges of >= P3D_FUSED_DYN_MIN_PLANES (64) planes,
+    // 2 wherever it is possible (>= 2 planes per block; the parity tests), 3 like 2 with P3D_FUSED_BLOCKS blocks (dev sweeps).
     if constexpr (kHasDyn) {
         if (rs_table && tn.fused_dyn > 0) {
             int nb = std::min(fused_resident_blocks<T, NC, RY>(), kRsMaxBlocks);
