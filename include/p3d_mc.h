@@ -17,7 +17,8 @@
  *     cursors and a 4 KiB pinned host mailbox through which the kernels report totals.  No torch types cross
  *     this boundary.
  *   - Threads: every entry point may be called concurrently from several host threads, on different streams or on
- *     ONE stream (each call with its own workspace and output buffers); the launches of a whole-grid
+ *     ONE stream (each call with its own workspace and output buffers; see p3d_mc_release_stream for what is kept per
+ *     stream); the launches of a whole-grid
  *     p3d_mc_extract_fused are enqueued under a per-stream lock, so calls sharing a stream queue up whole.
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All calls enqueue work on
  *     it and return immediately; p3d_mc_read_counts waits for the totals only (see there), not for the stream.
@@ -39,7 +40,7 @@
 extern "C" {
 #endif
 
-#define P3D_MC_ABI_VERSION 6
+#define P3D_MC_ABI_VERSION 7
 
 /* dtype of the scalar field */
 #define P3D_F32 0
@@ -199,6 +200,17 @@ const char* p3d_mc_profile_stage_name(int stage);
  * P3D_TEST_INDEX_LIMIT, P3D_NO_CHUNK_PRE, P3D_FUSED_DYN, P3D_FUSED_DYN_MIN_PLANES) are read from the environment ONCE, at
  * the first call; this re-reads them.  Not to be called while another thread is inside the library. */
 int p3d_mc_reload_tuning(void);
+
+/* Library-owned state (no reference counterpart: the reference keeps none, marching_cubes.cu:229-230 allocates its four
+ * counters per call).  Per (device, stream) the library keeps a ring of pre-cleared blocks (cursors of the streaming
+ * kernel, 0.5 MiB) and per device a 4 KiB pinned mailbox; both are created on first use.
+ *   p3d_mc_release_stream: frees what is kept for `stream` on the CURRENT device, after waiting for the work queued on it.
+ *       Call it before destroying a stream the library was used on; a later call on that stream simply creates the state
+ *       again.  Unknown streams are fine (returns 0).
+ *   p3d_mc_shutdown: frees everything (all devices and streams, the mailboxes, the profiling events).  No other thread may
+ *       be inside the library.  The library may be used again afterwards. */
+int p3d_mc_release_stream(void* stream);
+int p3d_mc_shutdown(void);
 
 /* Counters of what the library has launched since it was loaded (no reference counterpart; tests and the bench read them
  * to see which path a call took -- nothing in the data path depends on them):

@@ -16,7 +16,7 @@ SYMBOLS = ("p3d_mc_abi_version", "p3d_last_error", "p3d_mc_workspace_bytes", "p3
            "p3d_mc_read_counts", "p3d_mc_emit", "p3d_mc_plane_records", "p3d_mc_export_plane_records", "p3d_mc_profile_enable",
            "p3d_mc_profile_read", "p3d_mc_profile_stage_name", "p3d_mc_extract_fused", "p3d_mc_debug_layout",
            "p3d_mc_workspace_bytes_batched", "p3d_mc_extract_fused_batched", "p3d_mc_reload_tuning",
-           "p3d_mc_debug_counters")
+           "p3d_mc_debug_counters", "p3d_mc_release_stream", "p3d_mc_shutdown")
 
 
 class Slab(ctypes.Structure):
@@ -61,6 +61,7 @@ def lib():
         L.p3d_mc_debug_layout.argtypes = [c_int64, c_int64, c_int64, POINTER(c_size_t), POINTER(c_size_t),
                                           POINTER(c_int64), POINTER(c_int32)]
         L.p3d_mc_debug_counters.argtypes = [POINTER(c_int64), c_int]
+        L.p3d_mc_release_stream.argtypes = [c_void_p]
         L.p3d_mc_profile_enable.argtypes = [c_int]
         L.p3d_mc_profile_read.argtypes = [POINTER(c_float), c_int]
         L.p3d_mc_profile_stage_name.argtypes = [c_int]
@@ -142,6 +143,15 @@ def emit(grid, thresh, lower, upper, ws, vertices, faces, vertex_keys=None, slab
                                  c_void_p(faces.data_ptr()) if capf else None, capf,
                                  c_void_p(vertex_keys.data_ptr()) if vertex_keys is not None and capv else None,
                                  _stream_ptr(grid)), "p3d_mc_emit")
+
+
+def release_stream(stream_ptr):
+    """p3d_mc_release_stream: free what the library keeps for a stream (a raw hipStream_t as an int) on the current device."""
+    _check(lib().p3d_mc_release_stream(c_void_p(stream_ptr)), "p3d_mc_release_stream")
+
+
+def shutdown():
+    _check(lib().p3d_mc_shutdown(), "p3d_mc_shutdown")
 
 
 def debug_counters():

@@ -30,14 +30,28 @@ using torch::Tensor;
 
 namespace {
 
-// output-size hints of the one-pass path, per (device, grid shape)
+// output-size hints of the one-pass path, per (device, grid shape): the counts of the last kHintCalls calls on that shape.
+// The buffers of a call are sized for the LARGEST of them, so a sparse frame between two dense ones (per-frame extraction
+// of a changing field) does not make the next dense frame stream the field twice; after kHintCalls sparse calls in a row
+// the dense size is forgotten again.
 using CapKey = std::tuple<int, int64_t, int64_t, int64_t>;
+constexpr int kHintCalls = 4;
 struct CapHint {
-    int64_t nv, nf;
-    int slack_q;  // headroom of every scratch region in quarters (5 = 1.25x); grows after a region overflow
+    int64_t nv[kHintCalls] = {0, 0, 0, 0}, nf[kHintCalls] = {0, 0, 0, 0};
+    int n = 0;        // calls recorded (the ring's next slot is n % kHintCalls)
+    int slack_q = 5;  // headroom of every scratch region in quarters (5 = 1.25x); grows after a region overflow
+    uint64_t last_use = 0;
+    int64_t max_v() const { return *std::max_element(nv, nv + kHintCalls); }
+    int64_t max_f() const { return *std::max_element(nf, nf + kHintCalls); }
+    void record(int64_t v, int64_t f) {
+        nv[n % kHintCalls] = v;
+        nf[n % kHintCalls] = f;
+        ++n;
+    }
 };
-std::map<CapKey, CapHint> g_cap_hint;   // at most kMaxHints shapes; when full, the map is dropped (hints are only hints)
+std::map<CapKey, CapHint> g_cap_hint;   // at most kMaxHints shapes; when full, the least recently used one goes
 std::mutex g_cap_mu;
+uint64_t g_cap_clock = 0;
 constexpr size_t kMaxHints = 256;
 
 void check_rc(int rc, const char* what) {
@@ -124,8 +138,8 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
         std::lock_guard<std::mutex> g(g_cap_mu);
         auto it = g_cap_hint.find(key);
         if (it != g_cap_hint.end()) {
-            capv = it->second.nv + it->second.nv / 8 + 4096;
-            capf = it->second.nf + it->second.nf / 8 + 4096;
+            capv = it->second.max_v() + it->second.max_v() / 8 + 4096;
+            capf = it->second.max_f() + it->second.max_f() / 8 + 4096;
             slack_q = it->second.slack_q;
         } else {
             capv = std::max<int64_t>(4096, rx * ry * rz / 16);
@@ -136,8 +150,16 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     {
         // a field whose vertices are spread unevenly over the 32 regions gets more headroom per region next time
         std::lock_guard<std::mutex> g(g_cap_mu);
-        if (g_cap_hint.size() >= kMaxHints && g_cap_hint.find(key) == g_cap_hint.end()) g_cap_hint.clear();
-        g_cap_hint[key] = {nv, nf, region_overflow ? std::min(2 * slack_q, 32) : slack_q};
+        if (g_cap_hint.size() >= kMaxHints && g_cap_hint.find(key) == g_cap_hint.end()) {
+            auto oldest = g_cap_hint.begin();
+            for (auto it = g_cap_hint.begin(); it != g_cap_hint.end(); ++it)
+                if (it->second.last_use < oldest->second.last_use) oldest = it;
+            g_cap_hint.erase(oldest);
+        }
+        CapHint& h = g_cap_hint[key];
+        h.record(nv, nf);
+        h.slack_q = region_overflow ? std::min(2 * slack_q, 32) : slack_q;
+        h.last_use = ++g_cap_clock;
     }
     if (host_trace) {
         static double t_prev_out = 0.0;

@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <type_traits>
@@ -89,7 +90,8 @@ struct Ws {  // byte offsets into the workspace
 };
 
 constexpr int kBlock = 256;
-constexpr int kPreMinChunks = 1024;   // more face chunks than this: the counting kernel also leaves their exclusive prefix
+constexpr int kPreMinChunks = 1024;   // more face chunks than this: a one-block scan (k_chunk_prefix / k_stack_finish) leaves their
+                                      // exclusive prefix between the counting and the face launch
 constexpr int kHdrBytes = 8192;   // [0,256) totals/flags; [256,4352) the 32 cursors of a multi-part extraction (a whole-grid
                                   // call uses a block of the library's ring, see cursor_block_for); [4352,4608) prefixes
 // header slots (u64)
@@ -158,7 +160,7 @@ Ws make_ws(const Dims& d) {
     w.nchunks = w.cpi * d.nitems;
     w.chunk_sum = o;   // triangles per chunk
     o = align_up(o + (size_t)(w.nchunks + 1) * 4, 256);
-    w.chunk_pre = o;   // exclusive prefix of chunk_sum (written by the last counting block when there are many chunks)
+    w.chunk_pre = o;   // exclusive prefix of chunk_sum (by k_chunk_prefix / k_stack_finish when there are many chunks)
     o = align_up(o + (size_t)(w.nchunks + 1) * 4, 256);
     w.wave_off = o;    // first face of every (tile, wave), relative to its chunk
     o = align_up(o + (size_t)(w.nb_f + 1) * 4 * 4, 256);
@@ -967,7 +969,7 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     __shared__ u32 s_e0[3 * NS + 3];                     // plane x, per staged unit: {first id, offsets of the low half, of the high half}
     __shared__ u32 s_e1[2 * NS + 2];                     // plane x+1: {first id, y / z offsets of both halves in four bytes} (its x
                                                          // edges belong to the next cell layer: 2 dwords instead of 3)
-    __shared__ u32 s_ids[4][12][64];                     // per wave: vertex ids of the batch's cells' 12 edges; row 0 doubles as
+    __shared__ __attribute__((aligned(8))) u32 s_ids[4][12][64];   // per wave: vertex ids of the batch's cells' 12 edges; row 0 doubles as
                                                          // the batch's unit markers (read before the ids are written), and the
                                                          // launch's compaction blocks borrow a corner as their scratch
     __shared__ u32 s_tmp[4];
@@ -1432,12 +1434,21 @@ struct Tuning {
         test_id_limit, no_chunk_pre, test_index_limit, stack_nparts, stack_early, fused_dyn, dyn_min_planes;
 };
 Tuning read_tuning() {
-    return Tuning{env_int("P3D_FUSED_BLOCKS", 2048), env_int("P3D_FUSED_XT", -1), env_int("P3D_FUSED_XT_TAIL", -1),
+    Tuning t = Tuning{env_int("P3D_FUSED_BLOCKS", 2048), env_int("P3D_FUSED_XT", -1), env_int("P3D_FUSED_XT_TAIL", -1),
                   env_int("P3D_FUSED_TAIL_DIV", 4), env_int("P3D_FUSED_SPLIT_ROWS", 1), env_int("P3D_FUSED_SMALL16", 1),
                   env_int("P3D_COMPACT_BLOCKS", 256), env_int("P3D_COMPACT_EARLY", 3),
                   env_int("P3D_TEST_ID_LIMIT", 1 << 26), env_int("P3D_NO_CHUNK_PRE", 0),
                   env_int("P3D_TEST_INDEX_LIMIT", 0x7fffffff), env_int("P3D_STACK_NPARTS", -1), env_int("P3D_STACK_EARLY", -1),
                   env_int("P3D_FUSED_DYN", 0), env_int("P3D_FUSED_DYN_MIN_PLANES", 64)};
+    // (knobs that are divided by or used as counts: a zero or negative value from the environment means "the smallest legal")
+    t.fused_blocks = std::max(1, t.fused_blocks);
+    t.fused_tail_div = std::max(1, t.fused_tail_div);
+    t.compact_blocks = std::max(kRegions, t.compact_blocks);
+    t.compact_early = std::max(0, t.compact_early);
+    t.test_id_limit = std::max(1, t.test_id_limit);
+    t.test_index_limit = std::max(1, t.test_index_limit);
+    t.dyn_min_planes = std::max(2, t.dyn_min_planes);
+    return t;
 }
 Tuning g_tuning;
 std::once_flag g_tuning_once;
@@ -1463,8 +1474,10 @@ struct CursorRing {
     int cur = 0;
     std::mutex mu;   // held by a call from the moment it takes its block until its LAST kernel is enqueued
 };
+// (device, stream) -> ring.  shared_ptr: a call's lease keeps its ring alive while p3d_mc_release_stream / p3d_mc_shutdown
+// on another thread takes it out of the map.
 std::mutex g_ring_mu;
-std::vector<std::unique_ptr<CursorRing>> g_rings;
+std::map<std::pair<int, hipStream_t>, std::shared_ptr<CursorRing>> g_rings;
 
 // A call's hold on its stream's ring.  Two host threads may share one stream (through ctypes the GIL is released): the
 // block a call uses is cleared by the streaming kernel of the call BEFORE it in ring order, and is read by all three of
@@ -1472,6 +1485,7 @@ std::vector<std::unique_ptr<CursorRing>> g_rings;
 // the ring locked until the caller has enqueued its last kernel (a few tens of microseconds of host time; the GPU
 // serialises the stream anyway).
 struct RingLease {
+    std::shared_ptr<CursorRing> ring;
     std::unique_lock<std::mutex> lock;
 };
 
@@ -1479,27 +1493,44 @@ struct RingLease {
 int cursor_block_for(hipStream_t st, RingLease* lease, u64** block, u64** zero_next) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    CursorRing* r = nullptr;
+    std::shared_ptr<CursorRing> r;
     {
         std::lock_guard<std::mutex> g(g_ring_mu);
-        for (auto& e : g_rings)
-            if (e->dev == dev && e->stream == st) r = e.get();
-        if (!r) {
-            std::unique_ptr<CursorRing> n(new CursorRing);
+        auto it = g_rings.find({dev, st});
+        if (it != g_rings.end()) {
+            r = it->second;
+        } else {
+            std::shared_ptr<CursorRing> n(new CursorRing);
             n->dev = dev;
             n->stream = st;
             const size_t bytes = (size_t)kCursorRing * kRingSlotWords * sizeof(u64);
             HIP_TRY(hipMalloc((void**)&n->base, bytes));
-            HIP_TRY(hipMemsetAsync(n->base, 0, bytes, st));
+            if (hipMemsetAsync(n->base, 0, bytes, st) != hipSuccess) {
+                (void)hipFree(n->base);
+                return fail(P3D_EHIP, "hipMemsetAsync(cursor ring)%s");
+            }
             n->cur = kCursorRing - 1;
-            g_rings.push_back(std::move(n));
-            r = g_rings.back().get();
+            g_rings[{dev, st}] = n;
+            r = n;
         }
     }
+    lease->ring = r;
     lease->lock = std::unique_lock<std::mutex>(r->mu);
+    if (!r->base) return fail(P3D_EINVAL, "the stream's state was released while a call on it was starting%s");
     r->cur = (r->cur + 1) % kCursorRing;
     *block = r->base + (size_t)r->cur * kRingSlotWords;
     *zero_next = r->base + (size_t)((r->cur + 1) % kCursorRing) * kRingSlotWords;
+    return P3D_OK;
+}
+
+// frees one ring: waits for whoever is enqueueing on it, then for the stream's work (its kernels read and clear the blocks)
+int free_ring(const std::shared_ptr<CursorRing>& r, bool stream_alive) {
+    std::lock_guard<std::mutex> g(r->mu);
+    if (!r->base) return P3D_OK;
+    if (stream_alive) (void)hipStreamSynchronize(r->stream);
+    const hipError_t e = hipFree(r->base);   // (hipFree itself waits for the device: safe even after the stream is gone)
+    r->base = nullptr;
+    if (e != hipSuccess) return fail(P3D_EHIP, "hipFree(cursor ring): %s", hipGetErrorString(e));
     return P3D_OK;
 }
 
@@ -1895,7 +1926,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     u64* bits = (u64*)(ws + w.bits);
     uint2* rec = (uint2*)(ws + w.rec);
     u32 *csum = (u32*)(ws + w.chunk_sum), *woff = (u32*)(ws + w.wave_off);
-    // exclusive prefix of the chunk totals, written by the last counting block when there are many chunks
+    // exclusive prefix of the chunk totals, made by k_chunk_prefix between the two launches when there are many chunks
     // (P3D_NO_CHUNK_PRE=1: escape hatch and test reference -- every face tile adds the chunk totals up itself)
     u32* cpre = (w.nchunks > kPreMinChunks && !tuning().no_chunk_pre) ? (u32*)(ws + w.chunk_pre) : nullptr;
     // Vertex ids handed out by the streaming kernel are region * 2^26 + slot (a fixed stride, so they stay
@@ -2211,6 +2242,46 @@ int p3d_mc_reload_tuning(void) {   // dev / test hook: re-read the P3D_* knobs (
     (void)tuning();
     g_tuning = read_tuning();
     return P3D_OK;
+}
+
+int p3d_mc_release_stream(void* stream) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::shared_ptr<CursorRing> r;
+    {
+        std::lock_guard<std::mutex> g(g_ring_mu);
+        auto it = g_rings.find({dev, (hipStream_t)stream});
+        if (it == g_rings.end()) return P3D_OK;   // nothing was ever kept for it
+        r = it->second;
+        g_rings.erase(it);
+    }
+    return free_ring(r, true);
+}
+
+int p3d_mc_shutdown(void) {
+    int rc = P3D_OK;
+    std::map<std::pair<int, hipStream_t>, std::shared_ptr<CursorRing>> rings;
+    {
+        std::lock_guard<std::mutex> g(g_ring_mu);
+        rings.swap(g_rings);
+    }
+    for (auto& kv : rings)
+        if (int e = free_ring(kv.second, false)) rc = e;   // (streams may be gone already: hipFree waits for the device)
+    {
+        std::lock_guard<std::mutex> g(g_mb_mu);
+        for (auto& m : g_mb) {
+            if (m.host && hipHostFree(m.host) != hipSuccess) rc = fail(P3D_EHIP, "hipHostFree(mailbox)%s");
+            m = Mailbox();
+        }
+        for (auto& pc : g_pending) pc = PendingCall();
+    }
+    if (g_ev_made) {
+        for (int i = 0; i < ST_N; ++i)
+            for (int j = 0; j < 2; ++j) (void)hipEventDestroy(g_ev[i][j]);
+        g_ev_made = false;
+        g_prof_mode = 0;
+    }
+    return rc;
 }
 
 int p3d_mc_debug_counters(int64_t* out, int n) {

@@ -141,6 +141,8 @@ def marching_cubes_batched(density_grids, thresh: float, scale=None):
     ws = torch.empty(capi.workspace_bytes_batched(B, *shape), dtype=torch.uint8, device=dev)
     offs = torch.empty(2 * (B + 1), dtype=torch.int64, device=dev)
     key = (dev.index, B) + shape
+    if _BATCH_HINTS.get(key) == "per_item":   # (an earlier call found the batch's totals beyond int32)
+        return _batched_item_by_item(density_grids, thresh, lower, upper)
     capv, capf, slack = _BATCH_HINTS.get(key, (max(4096, nvox // 16), 2 * max(4096, nvox // 16), 5))
     for attempt in range(3):
         per_region = (capv + 32 * B - 1) // (32 * B)
@@ -155,12 +157,12 @@ def marching_cubes_batched(density_grids, thresh: float, scale=None):
             if e.code != capi.P3D_ERANGE:
                 raise
             # the TOTALS of the batch exceed int32 although face ids are local to an item: item by item, every item
-            # is checked against the limit on its own
+            # is checked against the limit on its own -- and later calls on this shape go there directly instead of
+            # allocating and streaming the whole batch first
+            _remember_batch(key, "per_item")
             break
         fitted = nv <= capv and nf <= capf and not flags
-        if len(_BATCH_HINTS) >= 256 and key not in _BATCH_HINTS:
-            _BATCH_HINTS.clear()
-        _BATCH_HINTS[key] = (nv + nv // 8 + 4096, nf + nf // 8 + 4096, min(32, 2 * slack) if flags & 1 else slack)
+        _remember_batch(key, (nv + nv // 8 + 4096, nf + nf // 8 + 4096, min(32, 2 * slack) if flags & 1 else slack))
         if fitted:  # (the offsets stay on the device like the meshes: no synchronisation inside the call)
             return v[:nv], f[:nf], offs[:B + 1], offs[B + 1:]
         if flags & 2:
@@ -169,7 +171,15 @@ def marching_cubes_batched(density_grids, thresh: float, scale=None):
     return _batched_item_by_item(density_grids, thresh, lower, upper)
 
 
-_BATCH_HINTS = {}   # (device, B, rx, ry, rz) -> (vertex capacity, face capacity, scratch slack in quarters)
+_BATCH_HINTS = {}   # (device, B, rx, ry, rz) -> (vertex capacity, face capacity, scratch slack in quarters) | "per_item"
+
+
+def _remember_batch(key, hint):
+    """At most 256 shapes; the oldest entry goes when a new shape arrives (dicts keep insertion order)."""
+    _BATCH_HINTS.pop(key, None)
+    if len(_BATCH_HINTS) >= 256:
+        _BATCH_HINTS.pop(next(iter(_BATCH_HINTS)))
+    _BATCH_HINTS[key] = hint
 
 
 def _batched_item_by_item(density_grids, thresh, lower, upper):

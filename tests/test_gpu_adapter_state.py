@@ -1,0 +1,128 @@
+"""State the adapter and the library keep BETWEEN calls (the reference keeps none: marching_cubes.cu:229-263 counts and
+allocates per call):
+
+  * output-size hints of the pybind adapter (csrc/bindings.cpp): the largest counts of the last four calls on a shape, so a
+    sparse frame does not make the next dense frame stream the field twice (the hint was the LAST call's);
+  * the per-stream cursor ring of libp3dmc.so: p3d_mc_release_stream / p3d_mc_shutdown give it back.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _passes():
+    from primitive3d_amd import capi
+    return capi.debug_counters()["streaming_passes"]
+
+
+def test_alternating_sparse_and_dense_frames_stream_once(gpu, built):
+    """sparse / dense / sparse / dense ... on one shape: from the third call on every call is ONE streaming pass."""
+    from primitive3d_amd.fields import perlin_grid
+    from tests.test_gpu_configs import torch_counts
+    shape = (250, 256, 256)   # (a shape no other test uses: its hints start empty)
+    dense = perlin_grid(shape, period=32, seed=3, device=gpu)
+    sparse = torch.ones(shape, device=gpu)   # all outside: V = F = 0
+    want = torch_counts(dense, 0.0)
+    assert want[0] > 100000
+    upper = [float(s) for s in shape]
+    per_call = []
+    for i in range(8):
+        g = dense if i & 1 else sparse
+        before = _passes()
+        v, f = built.libPrim3D.marching_cubes(g, 0.0, [0.0] * 3, upper)
+        per_call.append(_passes() - before)
+        assert (v.shape[0], f.shape[0]) == (want if i & 1 else (0, 0)), i
+    assert per_call[1] == 2, per_call        # the first dense frame: nothing but an empty frame to go by
+    assert per_call[2:] == [1] * 6, per_call
+
+
+def test_dense_size_is_forgotten_after_four_sparse_frames(gpu, built):
+    from primitive3d_amd.fields import perlin_grid
+    shape = (130, 256, 320)
+    dense = perlin_grid(shape, period=32, seed=4, device=gpu)
+    sparse = torch.ones(shape, device=gpu)
+    upper = [float(s) for s in shape]
+    seq = [dense, dense, sparse, sparse, sparse, dense, sparse, sparse, sparse, sparse, dense]
+    per_call = []
+    for g in seq:
+        before = _passes()
+        built.libPrim3D.marching_cubes(g, 0.0, [0.0] * 3, upper)
+        per_call.append(_passes() - before)
+    assert per_call[1] == 1 and per_call[5] == 1, per_call   # three sparse frames in between: still remembered
+    assert per_call[10] == 2, per_call                        # four: forgotten (buffers shrink again)
+
+
+def _hip():
+    lib = ctypes.CDLL("libamdhip64.so")
+    lib.hipStreamCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+    lib.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    return lib
+
+
+def test_release_stream_keeps_device_memory_flat(gpu, built):
+    """A C caller that creates a stream per job: 1000 streams, one extraction on each, p3d_mc_release_stream before the
+    stream is destroyed -> the device's free memory does not move (the ring of a stream is 0.5 MiB: 1000 kept rings would
+    be half a gigabyte).  Without the release the rings stay (that is what the entry point is for)."""
+    from primitive3d_amd import capi
+    hip = _hip()
+    g = torch.from_numpy(np.random.default_rng(0).standard_normal((6, 8, 70)).astype(np.float32)).to(gpu)
+    ws = torch.empty(capi.workspace_bytes(*g.shape), dtype=torch.uint8, device=gpu)
+    v = torch.empty((4096, 3), device=gpu)
+    f = torch.empty((8192, 3), dtype=torch.int32, device=gpu)
+    scratch = torch.empty((capi.scratch_rows_for(4096), 3), device=gpu)
+    want = None
+
+    def run_on(h):
+        nonlocal want
+        with torch.cuda.stream(torch.cuda.ExternalStream(h.value, device=gpu)):
+            capi.extract_fused_raw(g, 0.0, [0, 0, 0], [6, 8, 70], ws, v, f, scratch=scratch)
+            got = capi.read_counts(ws)
+        want = want or got
+        assert got == want and got[0] > 0
+
+    def create():
+        h = ctypes.c_void_p()
+        assert hip.hipStreamCreate(ctypes.byref(h)) == 0
+        return h
+
+    def job():
+        h = create()
+        run_on(h)
+        capi.release_stream(h.value)
+        assert hip.hipStreamDestroy(h) == 0
+
+    for _ in range(20):
+        job()   # (warm-up: allocator pools, the mailbox)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(gpu)[0]
+    for _ in range(1000):
+        job()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(gpu)[0]
+    assert abs(free0 - free1) <= 8 << 20, (free0, free1)
+    # 100 streams alive at once, none released: their rings are there ...
+    live = [create() for _ in range(100)]
+    for h in live:
+        run_on(h)
+    torch.cuda.synchronize()
+    free2 = torch.cuda.mem_get_info(gpu)[0]
+    assert free1 - free2 >= 30 << 20, (free1, free2)
+    # ... until they are released, one by one (the first half) or all at once by p3d_mc_shutdown (the rest)
+    for h in live[:50]:
+        capi.release_stream(h.value)
+    free3 = torch.cuda.mem_get_info(gpu)[0]
+    assert free3 - free2 >= 15 << 20, (free2, free3)
+    capi.shutdown()
+    free4 = torch.cuda.mem_get_info(gpu)[0]
+    assert free4 - free3 >= 15 << 20, (free3, free4)
+    for h in live:
+        assert hip.hipStreamDestroy(h) == 0
+    free5 = torch.cuda.mem_get_info(gpu)[0]   # (a live HIP stream holds about a megabyte of its own)
+    assert abs(free5 - free1) <= 16 << 20, (free1, free5)
+    # and the library works again afterwards (its state is created on first use)
+    capi.extract_fused_raw(g, 0.0, [0, 0, 0], [6, 8, 70], ws, v, f, scratch=scratch)
+    assert capi.read_counts(ws) == want

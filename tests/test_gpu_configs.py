@@ -163,12 +163,13 @@ def test_batched_call_falls_back_item_by_item(gpu, built, tuning_env):
 
 @pytest.mark.parametrize("kind", ["stack", "single"])
 def test_chunk_prefix_handoff_under_load(gpu, built, tuning_env, kind):
-    """With more than 1024 face chunks the LAST counting block to finish turns the chunk totals into their exclusive
-    prefix for k_faces (sc1 stores / loads and a drained store before the completion counter, no agent-scope fence:
-    p3d_mc.hip, k_face_count_walk).  A stale total would silently shift every face offset behind it.  Reference =
-    the same call with P3D_NO_CHUNK_PRE=1 (every face tile adds the totals up itself): the triangle soup must be
-    the same bit for bit (vertex ids are arrival order, so the soups are compared), counts equal to the independent torch count -- repeated,
-    back to back, so that the hand-off runs on a loaded chip with warm caches."""
+    """With more than 1024 face chunks a one-block scan between the counting and the face launch (k_chunk_prefix; for a
+    stack of items inside k_stack_finish) turns the chunk totals into their exclusive prefix, which every face tile then
+    reads instead of adding the totals in front of its chunk up (p3d_mc.hip).  A wrong prefix would silently shift every
+    face offset behind it.  Reference = the same call with P3D_NO_CHUNK_PRE=1 (every face tile adds the totals up itself):
+    the triangle soup must be the same bit for bit (vertex ids are arrival order, so the soups are compared), counts equal
+    to the independent torch count -- repeated, back to back, on a loaded chip with warm caches.  (Rounds 2-3 had the last
+    counting block make the prefix inside the launch, with a fence-free hand-off; that is gone, the test stayed.)"""
     from primitive3d_amd.fields import perlin_grid
     if kind == "stack":   # 20 items x 68 chunks = 1360 chunks
         grids = torch.stack([perlin_grid((130, 256, 256), period=32, seed=s, device=gpu).half() for s in range(20)])
@@ -204,12 +205,26 @@ def test_batch_whose_totals_exceed_int32_goes_item_by_item(gpu, built, tuning_en
     grids = torch.from_numpy(np.random.default_rng(8).standard_normal((3, 9, 10, 20)).astype(np.float32))
     counts = [oracle_count(grids[b].numpy(), 0.0) for b in range(3)]
     assert max(c[1] for c in counts) < 6000 < sum(c[1] for c in counts)
+    from primitive3d_amd import capi
+    from primitive3d_amd import marching_cubes as mcmod
     tuning_env("P3D_TEST_INDEX_LIMIT", "6000")
-    v, f, vo, fo = built.marching_cubes_batched(grids.to(gpu), 0.0)
-    for b in range(3):
-        assert (int(vo[b + 1] - vo[b]), int(fo[b + 1] - fo[b])) == counts[b]
-        fb = f[fo[b]:fo[b + 1]]
-        assert int(fb.min()) >= 0 and int(fb.max()) < counts[b][0]
+    key = (gpu.index, 3, 9, 10, 20)
+    try:
+        passes = []
+        for call in range(2):
+            before = capi.debug_counters()["streaming_passes"]
+            v, f, vo, fo = built.marching_cubes_batched(grids.to(gpu), 0.0)
+            passes.append(capi.debug_counters()["streaming_passes"] - before)
+            for b in range(3):
+                assert (int(vo[b + 1] - vo[b]), int(fo[b + 1] - fo[b])) == counts[b]
+                fb = f[fo[b]:fo[b + 1]]
+                assert int(fb.min()) >= 0 and int(fb.max()) < counts[b][0]
+        # the first call streams the whole batch once before it learns of the limit; the second goes item by item at once
+        # (it used to allocate and stream the batch again on every call)
+        assert mcmod._BATCH_HINTS.get(key) == "per_item"
+        assert passes[0] > passes[1] >= 3, passes
+    finally:
+        mcmod._BATCH_HINTS.pop(key, None)
 
 
 def test_c5_32x256_fp16_full_batch(gpu, built):
