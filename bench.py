@@ -152,7 +152,95 @@ def other_configs(p3d, capi, perlin_grid, dev):
                        "baseline of the 8-GPU target)",
             lambda: p3d.libPrim3D.marching_cubes(g4, 0.0, [0.0] * 3, [1024.0] * 3), 1024 ** 3, 4, steps=6)
     del g4
+    # SURVEY.md 8d, C3's secondary workload: four octaves (period 64 -> 8, persistence 0.5), about 6.5 % active cells
+    g6 = perlin_grid((512,) * 3, period=64, seed=0, octaves=4, persistence=0.5, device=dev)
+    measure("c3_4oct", "512x512x512 fp32 four-octave Perlin SDF (periods 64..8, persistence 0.5, seed 0), iso 0",
+            lambda: p3d.libPrim3D.marching_cubes(g6, 0.0, [0.0] * 3, [512.0] * 3), 512 ** 3, 4, steps=12)
+    del g6
+    # the reference's own input class at bench size: the examples/sphere.py:8-9 recipe (centre n/4, radius n/8; an object's
+    # SDF in a box -- most of the grid is far from the surface) at n = 512
+    ax = torch.arange(512, device=dev, dtype=torch.float32)
+    g7 = ((ax[:, None, None] - 128) ** 2 + (ax[None, :, None] - 128) ** 2 + (ax[None, None, :] - 128) ** 2 - 64.0 ** 2).contiguous()
+    measure("sphere512", "512x512x512 fp32 sphere field of examples/sphere.py:8-9 at n = 512 (centre 128, radius 64), iso 0",
+            lambda: p3d.libPrim3D.marching_cubes(g7, 0.0, [0.0] * 3, [512.0] * 3), 512 ** 3, 4, steps=20)
+    del g7
     torch.cuda.empty_cache()
+    return out
+
+
+def child_exact_mode(steps, warmup):
+    """`--child exact` (run by measure_modes in a fresh process with P3D_MC_MODE=exact): the adapter in the reference's own
+    call structure -- count pass, host read of (V, F), exact allocation, emit pass (marching_cubes.cu:242-287)."""
+    import torch
+    import primitive3d_amd as p3d
+    from primitive3d_amd import capi
+    from primitive3d_amd.fields import perlin_grid
+    dev = torch.device("cuda", 0)
+    g = perlin_grid(SHAPES[1], period=64, seed=0, device=dev)
+    up = [float(s) for s in SHAPES[1]]
+    for _ in range(warmup):
+        out = p3d.libPrim3D.marching_cubes(g, 0.0, [0.0] * 3, up)
+    torch.cuda.synchronize()
+    p0 = capi.debug_counters()["streaming_passes"]
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = p3d.libPrim3D.marching_cubes(g, 0.0, [0.0] * 3, up)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    print(json.dumps({"ms_per_step": round(ms, 4), "steps": steps,
+                      "streaming_passes_per_call": (capi.debug_counters()["streaming_passes"] - p0) / steps,
+                      "vertices": int(out[0].shape[0]), "faces": int(out[1].shape[0])}))
+
+
+def measure_modes(p3d, capi, grid, lower, upper):
+    """What a call costs OUTSIDE the steady state the headline measures (same grid, same boundary function; a few steps
+    each, after the headline's timed region):
+      exact            P3D_MC_MODE=exact in a fresh child process: count -> read -> exact allocation -> second pass, the
+                       reference's own structure (marching_cubes.cu:242-287)
+      sparse_dense     the field alternating with an all-outside grid of the same shape (per-frame extraction of a changing
+                       field): the adapter sizes its buffers for the largest of the last four calls, so every call is one pass
+      hint_miss        one dense call after four sparse ones (the dense size has been forgotten): the field is streamed
+                       twice -- what a too-small guess costs"""
+    import subprocess
+    import torch
+    out = {}
+    try:
+        env = dict(os.environ, P3D_MC_MODE="exact")
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--child", "exact", "--steps", "8", "--warmup", "3"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        out["exact"] = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:   # the headline must not depend on it
+        out["exact"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    sparse = torch.ones_like(grid)
+
+    def timed(g):
+        torch.cuda.synchronize()
+        p0, t0 = capi.debug_counters()["streaming_passes"], time.perf_counter()
+        p3d.libPrim3D.marching_cubes(g, 0.0, lower, upper)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3, capi.debug_counters()["streaming_passes"] - p0
+
+    for _ in range(2):
+        timed(sparse), timed(grid)
+    dense_t, sparse_t, passes = [], [], 0
+    for _ in range(6):
+        t, n = timed(sparse)
+        sparse_t.append(t)
+        passes += n
+        t, n = timed(grid)
+        dense_t.append(t)
+        passes += n
+    out["sparse_dense"] = {"dense_call_ms": round(sorted(dense_t)[len(dense_t) // 2], 4),
+                           "sparse_call_ms": round(sorted(sparse_t)[len(sparse_t) // 2], 4),
+                           "streaming_passes_per_call": passes / 12, "timing": "synchronised single calls (median of 6)"}
+    miss = []
+    for _ in range(3):
+        for _ in range(4):
+            timed(sparse)
+        miss.append(timed(grid))
+    out["hint_miss"] = {"dense_call_ms": round(sorted(t for t, _ in miss)[1], 4),
+                        "streaming_passes_per_call": sum(n for _, n in miss) / 3, "timing": "synchronised single calls (median of 3)"}
+    timed(grid)   # (leave the hints as the headline left them)
     return out
 
 
@@ -169,7 +257,12 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short c2 / c5 / c4-on-one-GPU measurements that follow the headline run")
     ap.add_argument("--stages", action="store_true", help="also print per-stage hipEvent times to stderr")
+    ap.add_argument("--no-modes", action="store_true",
+                    help="skip the short measurements of the call outside its steady state (`modes`) that follow the headline run")
+    ap.add_argument("--child", default="", help=argparse.SUPPRESS)   # (internal: measure_modes' fresh process)
     args = ap.parse_args()
+    if args.child == "exact":
+        return child_exact_mode(args.steps, args.warmup)
 
     import torch
     import torch.distributed as dist
@@ -332,11 +425,13 @@ def main():
         alg_bytes = local_vox * sizeof
         avg_ms = sum(dom_ms) / len(dom_ms)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = traffic_build = None
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists() and world == 1 and shape == SHAPES[1] and batch == 1 and args.config == "c3":  # this workload only
             try:
-                traffic = json.loads(tfile.read_text()).get("k_fused_hbm_bytes_per_launch")
+                tj = json.loads(tfile.read_text())
+                traffic = tj.get("k_fused_hbm_bytes_per_launch")
+                traffic_build = tj.get("build")   # the commit / library stamp the PMC passes were taken on
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": "k_fused", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -345,6 +440,7 @@ def main():
                     "whole_call_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if traffic:   # the same launch time against the bytes the kernel really moves (halo planes and rows, outputs)
             roofline["traffic_frac"] = round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            roofline["traffic_build"] = traffic_build   # (`traffic` is a committed PMC result of THAT build, not of this run)
         if call_ms:
             roofline["call_median_ms_hipevents"] = round(call_ms[len(call_ms) // 2], 4)
         roofline["cold_first_call_ms"] = round(cold_ms, 3)
@@ -364,6 +460,8 @@ def main():
                        "partition": "none" if world == 1 else f"axis-0 slabs x{world}, 1-plane RCCL halo"},
             "roofline": roofline,
         }
+        if world == 1 and args.config == "c3" and not args.size and not args.no_modes:
+            line["modes"] = measure_modes(p3d, capi, grid, lower, upper)
         if world == 1 and args.config == "c3" and not args.size and not args.no_other_configs:
             line["other_configs"] = other_configs(p3d, capi, perlin_grid, dev)
         if world == 1 and not args.no_cpu_baseline:

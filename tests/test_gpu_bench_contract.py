@@ -36,7 +36,8 @@ def test_bench_line_schema(gpu):
 
 def test_default_run_reports_the_other_configs(gpu):
     """The default run (the one the driver records) also times BASELINE.json's other single-GPU workloads for a few steps
-    each, after and outside the headline measurement, under `other_configs`; the headline fields stay what they were."""
+    each, after and outside the headline measurement, under `other_configs`, and the call outside its steady state under
+    `modes`; the headline fields stay what they were."""
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline"],
                          capture_output=True, text=True, timeout=900, cwd=str(ROOT))
     assert out.returncode == 0, out.stderr[-2000:]
@@ -48,11 +49,23 @@ def test_default_run_reports_the_other_configs(gpu):
     r = d["roofline"]
     assert r["traffic"] > r["alg_bytes_per_launch"] and r["frac"] <= r["traffic_frac"] < 1.0
     oc = d["other_configs"]
-    assert sorted(oc) == ["c2", "c4_1gpu", "c5"]
-    nvox = {"c2": 256 ** 3, "c5": 32 * 256 ** 3, "c4_1gpu": 1024 ** 3}
+    assert sorted(oc) == ["c2", "c3_4oct", "c4_1gpu", "c5", "sphere512"]
+    nvox = {"c2": 256 ** 3, "c5": 32 * 256 ** 3, "c4_1gpu": 1024 ** 3, "c3_4oct": 512 ** 3, "sphere512": 512 ** 3}
     for k, c in oc.items():
         assert c["unit"] == "Mvoxels/s" and c["ms_per_step"] > 0 and c["vertices"] > 0 and c["faces"] > 0, (k, c)
         assert abs(c["value"] - nvox[k] / (c["ms_per_step"] * 1e-3) / 1e6) / c["value"] < 0.01
         assert 0 < c["whole_call_frac"] < c["k_fused_frac"] < 1.0
     assert oc["c5"]["dtype"] == "f16" and oc["c2"]["dtype"] == "f32"
     assert (oc["c2"]["vertices"], oc["c2"]["faces"]) == (252218, 504432) or oc["c2"]["faces"] > 100000
+    # the four-octave field has about twice the surface of the single-octave one; the sphere of the reference's
+    # own example at n = 512 is a closed surface of radius 64 (V - F/2 = 2)
+    assert oc["c3_4oct"]["vertices"] > 1.5 * d["config"]["vertices"]
+    assert oc["sphere512"]["vertices"] - oc["sphere512"]["faces"] // 2 == 2 and oc["sphere512"]["faces"] % 2 == 0
+    # what a call costs outside the steady state
+    m = d["modes"]
+    assert sorted(m) == ["exact", "hint_miss", "sparse_dense"]
+    assert m["exact"]["streaming_passes_per_call"] == 2 and m["exact"]["ms_per_step"] > d["ms_per_step"]
+    assert (m["exact"]["vertices"], m["exact"]["faces"]) == (d["config"]["vertices"], d["config"]["faces"])
+    assert m["sparse_dense"]["streaming_passes_per_call"] == 1 and m["sparse_dense"]["dense_call_ms"] > m["sparse_dense"]["sparse_call_ms"] > 0
+    assert m["hint_miss"]["streaming_passes_per_call"] == 2 and m["hint_miss"]["dense_call_ms"] > m["sparse_dense"]["dense_call_ms"]
+    assert r["traffic_build"]

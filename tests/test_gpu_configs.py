@@ -88,6 +88,22 @@ def test_c3_whole_mesh_equals_the_oracle(gpu, built):
     assert np.array_equal(a, np.sort(rv.view([("", np.float32)] * 3), axis=0))
 
 
+def test_c3_four_octave_field_whole_mesh(gpu, built):
+    """SURVEY.md 8d, C3's secondary workload at full size: four octaves (period 64 -> 8, persistence 0.5), about twice the
+    surface of the single-octave field and much finer detail (more vertices per wave-plane, denser face tiles).  Whole mesh
+    against the oracle on all host cores, positions bit for bit."""
+    from primitive3d_amd.fields import perlin_grid
+    from oracle import oracle_extract
+    g = perlin_grid(512, period=64, seed=0, octaves=4, persistence=0.5, device=gpu)
+    v, f = built.marching_cubes(g, 0.0)
+    assert (v.shape[0], f.shape[0]) == torch_counts(g, 0.0) and v.shape[0] > 8_000_000
+    rv, rf, _ = oracle_extract(g.cpu().numpy(), 0.0, threads=0, want_keys=False)
+    assert v.shape[0] == rv.shape[0] and f.shape[0] == rf.shape[0]
+    assert torch.equal(soup_hashes(v, f), soup_hashes(torch.from_numpy(rv).to(gpu), torch.from_numpy(rf).to(gpu)))
+    a = np.sort(v.cpu().numpy().view([("", np.float32)] * 3), axis=0)
+    assert np.array_equal(a, np.sort(rv.view([("", np.float32)] * 3), axis=0))
+
+
 def test_c2_bunny_resampled_256(gpu, built):
     """bunny.npy (66^3) trilinearly resampled to 256^3 as SURVEY.md section 8d defines C2; native 66^3 counts too."""
     from pathlib import Path
@@ -206,7 +222,8 @@ def test_batch_whose_totals_exceed_int32_goes_item_by_item(gpu, built, tuning_en
     counts = [oracle_count(grids[b].numpy(), 0.0) for b in range(3)]
     assert max(c[1] for c in counts) < 6000 < sum(c[1] for c in counts)
     from primitive3d_amd import capi
-    from primitive3d_amd import marching_cubes as mcmod
+    import importlib
+    mcmod = importlib.import_module("primitive3d_amd.marching_cubes")   # (the package exports the FUNCTION of that name)
     tuning_env("P3D_TEST_INDEX_LIMIT", "6000")
     key = (gpu.index, 3, 9, 10, 20)
     try:

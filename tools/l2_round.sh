@@ -15,7 +15,7 @@ for ctrs in \
   "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_NC_READ_REQ_sum TCP_TCC_UC_READ_REQ_sum" \
   "TCC_STREAMING_REQ_sum TCC_NC_REQ_sum TCC_UC_REQ_sum TCC_CC_REQ_sum" ; do
   i=$((i+1))
-  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $O/l2$sfx$i -- python3 $R/bench.py --config $cfg --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $O/l2$sfx$i.log 2>&1
+  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $O/l2$sfx$i -- python3 $R/bench.py --config $cfg --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --no-modes > $O/l2$sfx$i.log 2>&1
 done
 python3 - <<PY > $O/l2_summary$sfx.txt
 import csv, glob, collections, subprocess
@@ -30,10 +30,9 @@ for f in glob.glob("$O/l2$sfx[0-9]/**/*counter_collection.csv", recursive=True):
                 break
         if k:
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-try:
-    head = subprocess.check_output(["git", "-C", "$R", "rev-parse", "HEAD"], text=True).strip()
-except Exception:
-    head = open("$R/primitive3d_amd/libp3dmc.so.stamp").read().strip()[:16] + " (library stamp)"
+import os
+head = open("$R/profiles/BUILD_ID").read().strip() if os.path.exists("$R/profiles/BUILD_ID") else \
+    "lib=" + open("$R/primitive3d_amd/libp3dmc.so.stamp").read().strip()[:16]
 print("build:", head, " config: $cfg  (per launch, mean of the last 3 launches of each pass)")
 for k, d in sorted(acc.items()):
     print("==", k)

@@ -11,7 +11,7 @@ for ctrs in \
   "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
   "SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_VALU_INT32" ; do
   i=$((i+1))
-  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $O/sq$sfx$i -- python3 $R/bench.py --config $cfg --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $O/sq$sfx$i.log 2>&1
+  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $O/sq$sfx$i -- python3 $R/bench.py --config $cfg --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --no-modes > $O/sq$sfx$i.log 2>&1
 done
 python3 - <<PY > $O/sq_summary$sfx.txt
 import csv, glob, collections
@@ -26,6 +26,8 @@ for f in glob.glob("$O/sq$sfx[0-9]/**/*counter_collection.csv", recursive=True):
                 break
         if k:
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+import os
+print("build:", open("$R/profiles/BUILD_ID").read().strip() if os.path.exists("$R/profiles/BUILD_ID") else "unknown")
 for k, d in sorted(acc.items()):
     print("==", k, "($cfg)")
     for c, v in sorted(d.items()):

@@ -7,6 +7,14 @@ import sys
 from collections import defaultdict
 
 d = sys.argv[1]
+# what was profiled: tools/gpu.sh leaves the commit and the library stamp in profiles/BUILD_ID before the snapshot travels
+# (.git stays behind); without it the library's own source digest
+from pathlib import Path
+_root = Path(__file__).resolve().parents[1]
+_bid = _root / "profiles" / "BUILD_ID"
+_stamp = _root / "primitive3d_amd" / "libp3dmc.so.stamp"
+BUILD = _bid.read_text().strip() if _bid.exists() else ("lib=" + _stamp.read_text().strip()[:16] if _stamp.exists() else "unknown")
+print("build:", BUILD)
 ours = ("k_fused", "k_face_count_walk", "k_face_total", "k_faces", "k_stack_finish", "k_export_plane_records", "k_scan_blocks", "k_classify",
         "k_unit_counts", "k_unit_records", "k_emit_vertices", "k_fix_records")
 
@@ -62,6 +70,7 @@ if "k_classify" in cf and cf["k_classify"] > 0:
         rd = fetch["k_fused"] * 1024 * corr
         wr = write.get("k_fused", 0) * 1024
         out = {"k_fused_hbm_bytes_per_launch": round(rd + wr), "k_fused_read_bytes": round(rd), "k_fused_write_bytes": round(wr),
-               "fetch_correction": round(corr, 4), "calibrated_on": "k_classify reading 512^3 fp32 once (known 536870912 B)"}
+               "fetch_correction": round(corr, 4), "calibrated_on": "k_classify reading 512^3 fp32 once (known 536870912 B)",
+               "build": BUILD}
         print(out)
 json.dump(out, open(d + "/traffic.json", "w"), indent=1)
