@@ -715,6 +715,17 @@ __global__ void __launch_bounds__(1024) k_stack_finish(const u64* __restrict__ c
 #ifndef P3D_COUNT_PB
 #define P3D_COUNT_PB 8   // planes per sub-batch of k_face_count_walk
 #endif
+#ifndef P3D_COUNT_STAMP   // dev-only: s_memtime stamps of every counting wave's phases -> a debug buffer (tools/dev/count_stamps.py)
+#define P3D_COUNT_STAMP 0
+#endif
+#if P3D_COUNT_STAMP
+__device__ u64* g_count_stamps = nullptr;   // [chunks * 4 waves][8]
+#define CSTAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); cstamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CSTAMP_NOWAIT(k) do { cstamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CSTAMP(k) do { } while (0)
+#define CSTAMP_NOWAIT(k) do { } while (0)
+#endif
 template <int PB>
 __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restrict__ bits, Dims d, int64_t tpp, int xw,
                                                             int cpi, u32* __restrict__ chunk_sum, u32* __restrict__ wave_off,
@@ -725,6 +736,11 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
         return;
     }
     __shared__ u32 s_part[PB][4];
+#if P3D_COUNT_STAMP
+    u64 cstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    CSTAMP_NOWAIT(0);
+    const u64 crt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t chunk = (int64_t)blockIdx.x - cp.nblocks;
     // chunks are numbered item by item (a single grid is one item): cpi chunks each, none straddles two items
@@ -765,6 +781,8 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
             Wp[i] = valid ? bits[u] : 0ull;
             Wq[i] = valid ? bits[u + d.ncz] : 0ull;
         });
+        CSTAMP_NOWAIT(1);   // all loads of the sub-batch issued (the compiler is free to move this stamp: read 1 + 2 together)
+        CSTAMP(2);          // ... and returned
         static_for<0, PB + 1>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             first |= ((u32)(Wp[i] & 1ull) | ((u32)(Wq[i] & 1ull) << 1)) << (2 * i);
@@ -809,7 +827,9 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
             n = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum(n), 63);
             if (lane == 0) s_part[i][wave] = n;
         });
+        CSTAMP(3);          // networks + per-plane wave sums done
         __syncthreads();
+        CSTAMP_NOWAIT(4);   // barrier passed
         // offsets of the sub-batch in one scan by the first wave: lane l = (plane i = l / 4, wave w = l % 4), so the
         // exclusive prefix over the lanes is "triangles of the chunk before wave w of plane i" (every lane keeps `running`)
         if (tid < 64) {
@@ -834,6 +854,15 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
     //  last counting block used to do that inside this launch; its hand-off -- an agent-scope store, a drained wait and a
     //  returning atomic per block -- cost every block about a microsecond: 110 -> 104 us on the 32 x 256^3 stack.)
     if (tid == 0) chunk_sum[chunk] = running;
+#if P3D_COUNT_STAMP
+    CSTAMP_NOWAIT(5);
+    if (lane == 0 && g_count_stamps) {
+        u64* o = g_count_stamps + ((size_t)chunk * 4 + wave) * 8;
+        for (int k = 0; k < 6; ++k) o[k] = cstamp[k];
+        o[6] = crt0;
+        o[7] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // F = sum of the chunk totals -> header + host mailbox (the counting call and the slab path; the one-pass call lets
@@ -2222,6 +2251,13 @@ int p3d_mc_debug_layout(int64_t rx, int64_t ry, int64_t rz, size_t* off_bits, si
     return P3D_OK;
 }
 
+#if P3D_COUNT_STAMP
+int p3d_mc_debug_count_stamps(void* buf) {   // dev build only: where k_face_count_walk leaves its per-wave phase stamps
+    u64* p = (u64*)buf;
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_count_stamps), &p, sizeof(p)));
+    return P3D_OK;
+}
+#endif
 #if P3D_FACES_STAMP
 int p3d_mc_debug_face_stamps(void* buf) {   // dev build only: where k_faces leaves its per-wave phase stamps
     u64* p = (u64*)buf;
