@@ -141,9 +141,13 @@ __device__ inline bool rs_steal(unsigned long long* table, uint32_t nb, uint32_t
         uint32_t ln = lane;
         asm volatile("" : "+v"(ln));   // (opaque per attempt: nothing below is hoisted out of the caller's loops)
         const uint32_t fib[16] = {1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233, 377, 610, 987, 1597};
-        uint32_t o = fib[ln & 15u] * (attempt ? 7u : 1u) % nb;
+        // (reduced with a mask, not a division by nb: the reciprocal of a run-time divisor is a vector register that would be
+        //  computed once per kernel and held -- spilled -- across the caller's hot loop)
+        const uint32_t pmask = (1u << (31 - __builtin_clz(nb))) - 1u;   // largest 2^n - 1 below nb  (nb >= 8)
+        uint32_t o = (fib[ln & 15u] * (attempt ? 7u : 1u)) & pmask;
         o = o == 0u ? 1u : o;
-        const uint32_t k = (ln & 16u) ? (me + nb - o) % nb : (me + o) % nb;
+        uint32_t k = (ln & 16u) ? me + nb - o : me + o;    // o < nb: one conditional subtraction wraps it
+        k = k >= nb ? k - nb : k;
         unsigned long long w = 0;
         if (ln < (uint32_t)kRsProbe && k != me) w = rs_load(table + (size_t)k * kRsStride);
         const uint32_t rem = rs_unclaimed(w);
