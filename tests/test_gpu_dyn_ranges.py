@@ -19,6 +19,11 @@ def _sphere(shape, c, r):
     return ((X - c[0]) ** 2 + (Y - c[1]) ** 2 + (Z - c[2]) ** 2 - r * r).astype(np.float32)
 
 
+def _perlin(shape, period, seed):
+    from primitive3d_amd.fields import perlin_grid
+    return perlin_grid(shape, period=period, seed=seed).numpy()
+
+
 CASES = {
     # (grid, thresh): rows of >= 5 chunks take the 8 x 3 tile, 3-4 chunks the 4 x 6 tile -- the two that have a DYN variant;
     # every shape has at least 2 planes per resident block (1024), or the launch falls back to fixed slabs
@@ -27,7 +32,7 @@ CASES = {
     "sphere_700x48x320_skewed_work": lambda: (_sphere((700, 48, 320), (60, 20, 100), 37.5), 0.0),   # most blocks idle: all steal
     "sphere_600x30x1200_three_z_tiles": lambda: (_sphere((600, 30, 1200), (250, 15, 600), 14.25), 0.0),
     "plateau_2100x13x321": lambda: (np.where(np.random.default_rng(3).random((2100, 13, 321)) < 0.5, 0.0, 1.0).astype(np.float32), 0.0),
-    "noise_1100x180x200_4x6_tile": lambda: (np.random.default_rng(4).standard_normal((1100, 180, 200)).astype(np.float32), -0.2),
+    "perlin_1100x180x200_4x6_tile": lambda: (_perlin((1100, 180, 200), 12, 4), -0.05),
 }
 
 
@@ -67,19 +72,23 @@ def test_dyn_and_fixed_slabs_agree_at_512_cubed(gpu, tuning_env, built):
 
 def test_dyn_stack_of_items(gpu, tuning_env, built):
     """A batch of grids is one stack of planes: under DYN the tile column carries the item, ranges never straddle items."""
-    rng = np.random.default_rng(11)
-    grids = torch.from_numpy(rng.standard_normal((6, 400, 100, 200)).astype(np.float32)).half()
+    from bench import soup_hashes
+    from primitive3d_amd.fields import perlin_grid
+    shape = (416, 100, 200)
+    grids = torch.stack([perlin_grid(shape, period=10 + 3 * b, seed=20 + b) for b in range(4)]).half()
     tuning_env("P3D_FUSED_DYN", 2)
     before = _dyn_launches()
-    v, f, vo, fo = built.marching_cubes_batched(grids.to(gpu), 0.1)
+    v, f, vo, fo = built.marching_cubes_batched(grids.to(gpu), 0.02)
     torch.cuda.synchronize()
     assert _dyn_launches() > before
-    soup = lambda vv, ff: np.sort(vv[ff.astype(np.int64)].reshape(len(ff), 9).view([("", np.float32)] * 9), axis=0)
+    vo, fo = vo.tolist(), fo.tolist()
     for b in range(grids.shape[0]):
-        rv, rf, _ = oracle_extract(grids[b].float().numpy(), 0.1, [0.0] * 3, [400.0, 100.0, 200.0])
-        vb, fb = v[vo[b]:vo[b + 1]].cpu().numpy(), f[fo[b]:fo[b + 1]].cpu().numpy()
-        assert vb.shape == rv.shape and fb.shape == rf.shape, (b, vb.shape, rv.shape)
-        assert np.array_equal(soup(vb, fb), soup(rv, rf)), b
+        rv, rf, _ = oracle_extract(grids[b].float().numpy(), 0.02, [0.0] * 3, [float(n) for n in shape], want_keys=False)
+        vb, fb = v[vo[b]:vo[b + 1]], f[fo[b]:fo[b + 1]]
+        assert tuple(vb.shape) == rv.shape and tuple(fb.shape) == rf.shape, (b, vb.shape, rv.shape)
+        hg, kg = soup_hashes(vb, fb)
+        ho, ko = soup_hashes(torch.from_numpy(rv).to(gpu), torch.from_numpy(rf).to(gpu))
+        assert torch.equal(kg, ko) and torch.equal(hg, ho), b
 
 
 def test_dyn_calls_back_to_back_reuse_cleared_tables(gpu, tuning_env, built):
