@@ -485,7 +485,9 @@ def main():
     if world > 1 and args.stages:
         # per-phase GPU time of the LAST step on every rank (halo wait, all-gather, record exchange, ...): what the first
         # real multi-GPU run needs to be diagnosable
-        print(f"rank {rank} phases (ms):", {k: round(v, 4) for k, v in ex.phase_times_ms().items()}, file=sys.stderr)
+        # (ONE write per rank: the ranks share stderr, and a line printed in pieces interleaves with the others')
+        sys.stderr.write(f"rank {rank} phases (ms): " + str({k: round(v, 4) for k, v in ex.phase_times_ms().items()}) + "\n")
+        sys.stderr.flush()
     if world > 1:
         dist.destroy_process_group()
 
