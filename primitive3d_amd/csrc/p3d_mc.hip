@@ -1460,7 +1460,8 @@ int env_int(const char* name, int dflt) {
 // first call (no getenv in the per-call host path); -1 = "use the built-in rule".
 struct Tuning {
     int fused_blocks, fused_xt, fused_xt_tail, fused_tail_div, split_rows, small16, compact_blocks, compact_early,
-        test_id_limit, no_chunk_pre, test_index_limit, stack_nparts, stack_early, fused_dyn, dyn_min_planes;
+        test_id_limit, no_chunk_pre, test_index_limit, stack_nparts, stack_early, fused_dyn, dyn_min_planes, fused_nbig, fused_nmid,
+        fused_xt_mid;
 };
 Tuning read_tuning() {
     Tuning t = Tuning{env_int("P3D_FUSED_BLOCKS", 2048), env_int("P3D_FUSED_XT", -1), env_int("P3D_FUSED_XT_TAIL", -1),
@@ -1468,7 +1469,8 @@ Tuning read_tuning() {
                   env_int("P3D_COMPACT_BLOCKS", 256), env_int("P3D_COMPACT_EARLY", 3),
                   env_int("P3D_TEST_ID_LIMIT", 1 << 26), env_int("P3D_NO_CHUNK_PRE", 0),
                   env_int("P3D_TEST_INDEX_LIMIT", 0x7fffffff), env_int("P3D_STACK_NPARTS", -1), env_int("P3D_STACK_EARLY", -1),
-                  env_int("P3D_FUSED_DYN", 0), env_int("P3D_FUSED_DYN_MIN_PLANES", 64)};
+                  env_int("P3D_FUSED_DYN", 0), env_int("P3D_FUSED_DYN_MIN_PLANES", 64), env_int("P3D_FUSED_NBIG", -1),
+                  env_int("P3D_FUSED_NMID", -1), env_int("P3D_FUSED_XT_MID", -1)};
     // (knobs that are divided by or used as counts: a zero or negative value from the environment means "the smallest legal")
     t.fused_blocks = std::max(1, t.fused_blocks);
     t.fused_tail_div = std::max(1, t.fused_tail_div);
@@ -1796,6 +1798,8 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
     g.x_lo = x_lo;
     g.x_hi = x_hi;
     g.nxt_item = 0;
+    g.n_mid = 0;
+    g.XT_mid = 1;
     g.cz_base = cz_base;   // chunks [cz_base, cz_base + cz_count) of every row (default: the whole row)
     if (cz_count < 0) cz_count = (int)d.ncz - cz_base;
     const bool stack = d.stack != 0;   // a batch of grids: every x-slab lies inside one item, all items in one launch
@@ -1863,15 +1867,22 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
     const int64_t nslab_all = (nplanes + xt - 1) / xt;
     int64_t n_big = nslab_all - std::max<int64_t>(1, nslab_all / std::max(1, tn.fused_tail_div));
     if (xt_tail >= xt || nslab_all < 8) n_big = nslab_all;
+    if (tn.fused_nbig >= 0) n_big = std::min<int64_t>(tn.fused_nbig, nslab_all);
     g.n_big = (int)n_big;
     g.XT_tail = xt_tail > 0 ? xt_tail : 1;
-    const int64_t rest = nplanes - n_big * xt;
-    g.nxt = (int)(n_big + (rest > 0 ? (rest + g.XT_tail - 1) / g.XT_tail : 0));
+    int64_t rest = nplanes - n_big * xt;
+    g.XT_mid = tn.fused_xt_mid > 0 ? tn.fused_xt_mid : std::max(1, xt / 2);
+    // (rule: the first two thirds of what the big slabs leave)
+    const int64_t want_mid = tn.fused_nmid >= 0 ? tn.fused_nmid : (g.XT_mid > g.XT_tail && g.XT_mid < xt ? rest * 2 / 3 / g.XT_mid : 0);
+    g.n_mid = (int)std::max<int64_t>(0, std::min<int64_t>(want_mid, rest / g.XT_mid));
+    rest -= (int64_t)g.n_mid * g.XT_mid;
+    g.nxt = (int)(n_big + g.n_mid + (rest > 0 ? (rest + g.XT_tail - 1) / g.XT_tail : 0));
     if (stack) {   // uniform slabs, no taper (many items: the tail of the launch is short anyway)
         g.nxt_item = (int)((nplanes + xt - 1) / xt);
         g.nxt = g.nxt_item;   // (per_slab already counts the items)
         g.n_big = g.nxt;
         g.XT_tail = xt;
+        g.n_mid = 0;
     }
     const int64_t nblocks = per_slab * g.nxt;
     const RsGeom rs0 = rs_make_geom(1, 1, 1);

@@ -2,7 +2,7 @@
 persistent blocks to get at least two planes each, fields from dense noise to a small object in a box (most blocks idle:
 everything is stolen), fp32 and fp16."""
 import os, sys
-os.environ["P3D_FUSED_DYN"] = "2"
+os.environ.setdefault("P3D_FUSED_DYN", "2")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import numpy as np, torch
 from oracle import oracle_extract
