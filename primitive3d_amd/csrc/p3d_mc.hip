@@ -1862,7 +1862,8 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
     if (xt < 1) xt = 1;
     if (xt > nplanes) xt = (int)nplanes;
     g.XT = xt;
-    // taper: the last ~1/8 of the planes go in slabs of XT/4 planes
+    // taper: the last quarter of the long slabs is replaced by slabs of XT/2 planes (two thirds of those planes) and of XT/4
+    // planes (the rest) -- profiles/r04/dyn_ranges.txt section 11
     const int xt_tail = tn.fused_xt_tail >= 0 ? tn.fused_xt_tail : (xt >= 4 ? xt / 4 : xt);
     const int64_t nslab_all = (nplanes + xt - 1) / xt;
     int64_t n_big = nslab_all - std::max<int64_t>(1, nslab_all / std::max(1, tn.fused_tail_div));
