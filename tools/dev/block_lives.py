@@ -6,9 +6,11 @@ import torch, numpy as np
 from primitive3d_amd import capi
 from primitive3d_amd.fields import perlin_grid
 N = int(os.environ.get("N", "512"))
-g = perlin_grid(N, device="cuda")
-ws = torch.empty(capi.workspace_bytes(N, N, N), dtype=torch.uint8, device="cuda")
-v = torch.empty((N ** 3 // 16, 3), device="cuda"); f = torch.empty((N ** 3 // 8, 3), dtype=torch.int32, device="cuda")
+shape = tuple(int(v) for v in os.environ["SHAPE"].split(",")) if os.environ.get("SHAPE") else (N, N, N)
+nvox = shape[0] * shape[1] * shape[2]
+g = perlin_grid(shape, device="cuda")
+ws = torch.empty(capi.workspace_bytes(*shape), dtype=torch.uint8, device="cuda")
+v = torch.empty((nvox // 16, 3), device="cuda"); f = torch.empty((nvox // 8, 3), dtype=torch.int32, device="cuda")
 buf = torch.zeros((16384, 8), dtype=torch.int64, device="cuda")
 L = capi.lib()
 L.p3d_mc_debug_rs_stats.argtypes = [ctypes.c_void_p]
@@ -16,7 +18,7 @@ assert L.p3d_mc_debug_rs_stats(ctypes.c_void_p(buf.data_ptr())) == 0
 capi.profile_enable(2)
 for _ in range(4):
     buf.zero_()
-    capi.extract_fused_raw(g, 0.0, [0, 0, 0], [N] * 3, ws, v, f)
+    capi.extract_fused_raw(g, 0.0, [0, 0, 0], list(shape), ws, v, f)
     capi.read_counts(ws)
     torch.cuda.synchronize()
     st = capi.profile_read()
@@ -35,3 +37,13 @@ for t, (n, w) in zip(edges, alive):
     print("  %5.0f - %5.0f : %6.1f %s" % (t, t + 5, w, "#" * int(w / 16)))
 print("slot-time used: %.0f block-us = %.1f us x 1024 slots; idle slot-time inside the span: %.1f us x 1024" %
       ((b - a).sum(), (b - a).sum() / 1024, b.max() - (b - a).sum() / 1024))
+
+# long blocks only: how long a plane takes as a function of WHEN the block ran
+big = pl >= max(4, int(np.percentile(pl, 90)) - 1)
+print("blocks of >= %d planes: us per plane load (life / (planes + 1)) by start time" % pl[big].min())
+w = float(os.environ.get("BUCKET", "10"))
+for t in np.arange(0, a[big].max() + w, w):
+    m = big & (a >= t) & (a < t + w)
+    if m.sum():
+        r = (b[m] - a[m]) / (pl[m] + 1)
+        print("  start %5.0f - %5.0f : %5d blocks  median %.2f  p10 %.2f  p90 %.2f" % (t, t + w, m.sum(), np.median(r), np.percentile(r, 10), np.percentile(r, 90)))

@@ -12,7 +12,9 @@ capv = shape[0] * shape[1] * shape[2] // 16
 v = torch.empty((capv, 3), device="cuda"); f = torch.empty((2 * capv, 3), dtype=torch.int32, device="cuda")
 capi.profile_enable(2)
 acc = {}
-for i in range(8):
+flush = torch.empty(int(os.environ.get("FLUSH_MB", "0")) << 20, dtype=torch.uint8, device="cuda")   # FLUSH_MB: written between calls (what the
+for i in range(8):                                                                                   # memory-side cache keeps of the grid from call to call)
+    if flush.numel(): sink = flush.view(torch.int32).sum() if os.environ.get("FLUSH_READ", "1") != "0" else flush.fill_(i)   # (a READ: clean lines, no write-back traffic under the next kernel)
     capi.extract_fused_raw(g, 0.0, [0, 0, 0], list(shape), ws, v, f)
     nv, nf = capi.read_counts(ws)
     torch.cuda.synchronize()
