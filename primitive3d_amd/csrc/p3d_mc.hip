@@ -492,6 +492,9 @@ struct FaceArgs {
     u64 seq;
     FastDiv div_tpp = {1, 0, 0}, div_xper = {1, 0, 0}, div_ncz = {1, 0, 0};   // (filled in by launch_faces)
     int xw_shift = 0;                                                           // log2(xw)
+    int sparse = 0;   // the caller expects few triangles per tile (launch_faces, from the face capacity): a block first asks
+                      // for its tile's triangle count alone -- one scalar load -- and an empty tile leaves before any of the
+                      // prologue's vector loads is issued
 };
 
 __device__ inline void wave_lds_sync() {  // orders one wave's LDS traffic across its lanes (no block barrier)
@@ -1023,10 +1026,16 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
         pin64((u64)a.chunk_sum); pin64((u64)a.chunk_pre); pin64((u64)a.wave_off); pin64((u64)a.tile_tris);
         pin64((u64)a.cursors); pin64((u64)a.rank_counts); pin64((u64)bits); pin64((u64)rec);
     }
-    const bool XLATE = a.xlate == 1 || (a.xlate == 2 && hdr[H_RECFORM] != 0ull);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // (32-bit index arithmetic by multiply-high: three divisions by run-time constants)
     const u32 b = (u32)blockIdx.x - (u32)cp.nblocks;
+    // sparse fields (an object's SDF in a box: nearly every tile is empty): the tile's count by a scalar load, in front of
+    // everything -- an empty tile's block lives for one scalar round trip instead of issuing its 17 vector loads per lane and
+    // waiting for the first (sphere in 512^3: 21.6 -> 15.2 us).  On a dense field it costs a round trip per block in front
+    // of the prologue (512^3 noise: 67.6 -> 68.1 us over three runs each), so only launches that expect few triangles per
+    // tile take it.
+    if (a.sparse && a.tile_tris[b] == 0u) return;
+    const bool XLATE = a.xlate == 1 || (a.xlate == 2 && hdr[H_RECFORM] != 0ull);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 x32 = fd_div(b, a.div_tpp);
     const int64_t x = x32;
     const int64_t tile = b - x32 * (u32)a.tpp;
@@ -1673,6 +1682,10 @@ void launch_count_walk(dim3 grid, hipStream_t st, const u64* bits, const Dims& d
 }
 
 // the face launch: with `faces_here` one block per face tile, else the compaction blocks only
+inline int env_int_cached_faces_sparse() {   // P3D_FACES_SPARSE: -1 the rule in launch_faces (default), 0 never, 1 always (dev A/B)
+    static const int v = env_int("P3D_FACES_SPARSE", -1);
+    return v;
+}
 void launch_faces(const Dims& d, const Ws& w, const u64* bits, const uint2* rec, const FaceArgs& a_in, const CompactArgs& cp,
                   u64* hdr, int32_t* faces, int64_t capf, bool faces_here, hipStream_t st) {
     const dim3 fgrid((u32)((faces_here ? w.nb_f : 0) + cp.nblocks));
@@ -1682,6 +1695,10 @@ void launch_faces(const Dims& d, const Ws& w, const u64* bits, const uint2* rec,
     a.div_xper = make_fastdiv((u32)d.xper);
     a.div_ncz = make_fastdiv((u32)d.ncz);
     a.xw_shift = __builtin_ctz((unsigned)w.xw);
+    // (by the capacity the caller sized for its expectation: fewer than 128 triangles per tile on average -- at 512^3 a noise
+    //  field has 1270 per tile, a sphere 19)
+    const int sparse_knob = env_int_cached_faces_sparse();
+    a.sparse = sparse_knob >= 0 ? sparse_knob : (faces_here && capf < (int64_t)w.nb_f * 128 ? 1 : 0);
     if (d.ncz <= 32)
         hipLaunchKernelGGL(k_faces<32>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
     else

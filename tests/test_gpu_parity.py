@@ -305,6 +305,36 @@ def test_adapter_modes_in_a_fresh_process(gpu, env):
         assert nv <= got[2] <= nv + nv // 8 + 4096 and nf <= got[3] <= nf + nf // 8 + 4096, got
 
 
+@pytest.mark.parametrize("knob", ["0", "1"])
+def test_face_tiles_scalar_precheck_both_ways(gpu, knob):
+    """k_faces asks for its tile's triangle count by a scalar load first when the launch expects few triangles per tile
+    (FaceArgs::sparse; by default decided from the face capacity, i.e. after the first call on a sphere-in-a-box field).
+    P3D_FACES_SPARSE forces it off / on for every launch (read once per process): a sparse and a dense field must give the
+    same meshes either way -- compared with the oracle's as sorted triangle soups."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    code = ("import sys, torch, numpy as np; sys.path.insert(0, %r)\n"
+            "import primitive3d_amd as p3d\n"
+            "from bench import soup_hashes\n"
+            "from primitive3d_amd.fields import sphere_grid, perlin_grid\n"
+            "from oracle import oracle_extract\n"
+            "for name, g in (('sphere', torch.tensor(sphere_grid(96)).float().cuda()), ('noise', perlin_grid((70, 64, 130), period=16, seed=5, device='cuda'))):\n"
+            "    up = [float(s) for s in g.shape]\n"
+            "    for _ in range(3):\n"
+            "        v, f = p3d.libPrim3D.marching_cubes(g, 0.0, [0.0] * 3, up)\n"
+            "    ov, of = oracle_extract(g.cpu().numpy(), 0.0, [0.0] * 3, up)[:2]\n"
+            "    a = soup_hashes(v, f); b = soup_hashes(torch.from_numpy(ov).cuda(), torch.from_numpy(of.astype(np.int32)).cuda())\n"
+            "    assert v.shape[0] == ov.shape[0] and f.shape[0] == of.shape[0] and f.shape[0] > 0, name\n"
+            "    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), name\n"
+            "print('ok')\n") % str(root)
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, "P3D_FACES_SPARSE": knob}, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
 def test_threads_sharing_one_stream_through_the_c_abi(gpu, built):
     """Four host threads enqueue whole extractions on ONE stream through ctypes (which releases the GIL, so the calls
     really interleave on the host): the library hands every call a block of the stream's cursor ring and the streaming
