@@ -197,7 +197,8 @@ const char* p3d_mc_profile_stage_name(int stage);
 /* Developer / test hook (no reference counterpart).  The launch-shape knobs of the developer sweeps and the two test
  * hooks (P3D_FUSED_BLOCKS, P3D_FUSED_XT, P3D_FUSED_XT_TAIL, P3D_FUSED_TAIL_DIV, P3D_FUSED_SPLIT_ROWS,
  * P3D_FUSED_SMALL16, P3D_COMPACT_BLOCKS, P3D_COMPACT_EARLY, P3D_STACK_NPARTS, P3D_STACK_EARLY, P3D_TEST_ID_LIMIT,
- * P3D_TEST_INDEX_LIMIT, P3D_NO_CHUNK_PRE, P3D_FUSED_DYN, P3D_FUSED_DYN_MIN_PLANES) are read from the environment ONCE, at
+ * P3D_TEST_INDEX_LIMIT, P3D_NO_CHUNK_PRE, P3D_FUSED_DYN, P3D_FUSED_DYN_MIN_PLANES, P3D_FUSED_NBIG, P3D_FUSED_NMID,
+ * P3D_FUSED_XT_MID, P3D_FACES_SPARSE) are read from the environment ONCE, at
  * the first call; this re-reads them.  Not to be called while another thread is inside the library. */
 int p3d_mc_reload_tuning(void);
 

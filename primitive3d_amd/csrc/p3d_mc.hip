@@ -1470,7 +1470,7 @@ int env_int(const char* name, int dflt) {
 struct Tuning {
     int fused_blocks, fused_xt, fused_xt_tail, fused_tail_div, split_rows, small16, compact_blocks, compact_early,
         test_id_limit, no_chunk_pre, test_index_limit, stack_nparts, stack_early, fused_dyn, dyn_min_planes, fused_nbig, fused_nmid,
-        fused_xt_mid;
+        fused_xt_mid, faces_sparse;
 };
 Tuning read_tuning() {
     Tuning t = Tuning{env_int("P3D_FUSED_BLOCKS", 2048), env_int("P3D_FUSED_XT", -1), env_int("P3D_FUSED_XT_TAIL", -1),
@@ -1479,7 +1479,8 @@ Tuning read_tuning() {
                   env_int("P3D_TEST_ID_LIMIT", 1 << 26), env_int("P3D_NO_CHUNK_PRE", 0),
                   env_int("P3D_TEST_INDEX_LIMIT", 0x7fffffff), env_int("P3D_STACK_NPARTS", -1), env_int("P3D_STACK_EARLY", -1),
                   env_int("P3D_FUSED_DYN", 0), env_int("P3D_FUSED_DYN_MIN_PLANES", 64), env_int("P3D_FUSED_NBIG", -1),
-                  env_int("P3D_FUSED_NMID", -1), env_int("P3D_FUSED_XT_MID", -1)};
+                  env_int("P3D_FUSED_NMID", -1), env_int("P3D_FUSED_XT_MID", -1),
+                  env_int("P3D_FACES_SPARSE", -1)};
     // (knobs that are divided by or used as counts: a zero or negative value from the environment means "the smallest legal")
     t.fused_blocks = std::max(1, t.fused_blocks);
     t.fused_tail_div = std::max(1, t.fused_tail_div);
@@ -1682,10 +1683,6 @@ void launch_count_walk(dim3 grid, hipStream_t st, const u64* bits, const Dims& d
 }
 
 // the face launch: with `faces_here` one block per face tile, else the compaction blocks only
-inline int env_int_cached_faces_sparse() {   // P3D_FACES_SPARSE: -1 the rule in launch_faces (default), 0 never, 1 always (dev A/B)
-    static const int v = env_int("P3D_FACES_SPARSE", -1);
-    return v;
-}
 void launch_faces(const Dims& d, const Ws& w, const u64* bits, const uint2* rec, const FaceArgs& a_in, const CompactArgs& cp,
                   u64* hdr, int32_t* faces, int64_t capf, bool faces_here, hipStream_t st) {
     const dim3 fgrid((u32)((faces_here ? w.nb_f : 0) + cp.nblocks));
@@ -1697,7 +1694,7 @@ void launch_faces(const Dims& d, const Ws& w, const u64* bits, const uint2* rec,
     a.xw_shift = __builtin_ctz((unsigned)w.xw);
     // (by the capacity the caller sized for its expectation: fewer than 128 triangles per tile on average -- at 512^3 a noise
     //  field has 1270 per tile, a sphere 19)
-    const int sparse_knob = env_int_cached_faces_sparse();
+    const int sparse_knob = tuning().faces_sparse;   // (P3D_FACES_SPARSE: -1 the rule, 0 never, 1 always -- dev A/B, tests)
     a.sparse = sparse_knob >= 0 ? sparse_knob : (faces_here && capf < (int64_t)w.nb_f * 128 ? 1 : 0);
     if (d.ncz <= 32)
         hipLaunchKernelGGL(k_faces<32>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
