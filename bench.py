@@ -192,6 +192,57 @@ def child_exact_mode(steps, warmup):
                       "vertices": int(out[0].shape[0]), "faces": int(out[1].shape[0])}))
 
 
+def child_stream(steps, warmup):
+    """`--child stream` (run under rocprofv3 --pmc by measure_traffic_live): the headline's call, a few times, nothing else."""
+    import torch
+    import primitive3d_amd as p3d
+    from primitive3d_amd.fields import perlin_grid
+    g = perlin_grid(SHAPES[1], period=64, seed=0, device=torch.device("cuda", 0))
+    up = [float(s) for s in SHAPES[1]]
+    for _ in range(warmup + steps):
+        p3d.libPrim3D.marching_cubes(g, 0.0, [0.0] * 3, up)
+    torch.cuda.synchronize()
+
+
+def measure_traffic_live():
+    """The bytes `k_fused` moves over the fabric per launch, measured in THIS run: two `rocprofv3 --pmc` passes (counters
+    only, with --kernel-trace: the combination the GPU pool allows) over a child process that makes the headline's call
+    seven times -- reads as L2 -> fabric read requests BY REQUEST SIZE (32 / 64 / 128 B: no correction factor; FETCH_SIZE
+    tallies a 128-byte request at 64 bytes on gfx950, MI355X_MICROARCH.md "HBM"), writes as WRITE_SIZE (KiB, exact for
+    streaming stores, same section).  Mean of the last three launches.  None when rocprofv3 is not there or a pass fails
+    (the committed profiles/traffic.json is reported instead, labelled)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3") or any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None   # (not there, or this process is itself being profiled)
+    passes = {"rd": ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"],
+              "wr": ["WRITE_SIZE"]}
+    got = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            for tag, ctrs in passes.items():
+                cmd = ["rocprofv3", "--pmc", *ctrs, "--kernel-trace", "--output-format", "csv", "-d", f"{td}/{tag}", "--",
+                       sys.executable, str(ROOT / "bench.py"), "--child", "stream", "--steps", "5", "--warmup", "2"]
+                subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=300)
+                acc = {}
+                for f in glob.glob(f"{td}/{tag}/**/*counter_collection.csv", recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        if "k_fused" in r["Kernel_Name"]:
+                            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                for c, v in acc.items():
+                    got[c] = sum(v[-3:]) / len(v[-3:])
+        rd = 32 * got["TCC_EA0_RDREQ_32B_sum"] + 64 * got["TCC_EA0_RDREQ_64B_sum"] + 128 * got["TCC_EA0_RDREQ_128B_sum"]
+        wr = 1024 * got["WRITE_SIZE"]
+        if rd <= 0 or wr <= 0:
+            return None
+        return {"read": int(rd), "write": int(wr)}
+    except Exception:
+        return None
+
+
 def measure_modes(p3d, capi, grid, lower, upper):
     """What a call costs OUTSIDE the steady state the headline measures (same grid, same boundary function; a few steps
     each, after the headline's timed region):
@@ -259,10 +310,15 @@ def main():
     ap.add_argument("--stages", action="store_true", help="also print per-stage hipEvent times to stderr")
     ap.add_argument("--no-modes", action="store_true",
                     help="skip the short measurements of the call outside its steady state (`modes`) that follow the headline run")
-    ap.add_argument("--child", default="", help=argparse.SUPPRESS)   # (internal: measure_modes' fresh process)
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure `roofline.traffic` in this run (two rocprofv3 --pmc child passes, ~20 s): report the "
+                         "committed profiles/traffic.json instead")
+    ap.add_argument("--child", default="", help=argparse.SUPPRESS)   # (internal: measure_modes' / measure_traffic_live's fresh process)
     args = ap.parse_args()
     if args.child == "exact":
         return child_exact_mode(args.steps, args.warmup)
+    if args.child == "stream":
+        return child_stream(args.steps, args.warmup)
 
     import torch
     import torch.distributed as dist
@@ -427,7 +483,11 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = traffic_build = None
         tfile = ROOT / "profiles" / "traffic.json"
-        if tfile.exists() and world == 1 and shape == SHAPES[1] and batch == 1 and args.config == "c3":  # this workload only
+        headline = world == 1 and shape == SHAPES[1] and batch == 1 and args.config == "c3"   # this workload only
+        live = measure_traffic_live() if headline and not args.no_live_traffic else None
+        if live:
+            traffic = live["read"] + live["write"]
+        elif tfile.exists() and headline:
             try:
                 tj = json.loads(tfile.read_text())
                 traffic = tj.get("k_fused_hbm_bytes_per_launch")
@@ -440,7 +500,13 @@ def main():
                     "whole_call_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if traffic:   # the same launch time against the bytes the kernel really moves (halo planes and rows, outputs)
             roofline["traffic_frac"] = round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-            roofline["traffic_build"] = traffic_build   # (`traffic` is a committed PMC result of THAT build, not of this run)
+            if live:
+                roofline["traffic_read"], roofline["traffic_write"] = live["read"], live["write"]
+                roofline["traffic_source"] = ("this run: rocprofv3 --pmc over a child making the same call (fabric read requests by "
+                                              "request size; WRITE_SIZE), k_fused, mean of the last 3 of 7 launches")
+            else:
+                roofline["traffic_source"] = "profiles/traffic.json (a committed PMC result of the build named in traffic_build, not of this run)"
+                roofline["traffic_build"] = traffic_build
         if call_ms:
             roofline["call_median_ms_hipevents"] = round(call_ms[len(call_ms) // 2], 4)
         roofline["cold_first_call_ms"] = round(cold_ms, 3)

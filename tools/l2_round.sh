@@ -15,7 +15,7 @@ for ctrs in \
   "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_NC_READ_REQ_sum TCP_TCC_UC_READ_REQ_sum" \
   "TCC_STREAMING_REQ_sum TCC_NC_REQ_sum TCC_UC_REQ_sum TCC_CC_REQ_sum" ; do
   i=$((i+1))
-  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $O/l2$sfx$i -- python3 $R/bench.py --config $cfg --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --no-modes > $O/l2$sfx$i.log 2>&1
+  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $O/l2$sfx$i -- python3 $R/bench.py --config $cfg --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --no-modes --no-live-traffic > $O/l2$sfx$i.log 2>&1
 done
 python3 - <<PY > $O/l2_summary$sfx.txt
 import csv, glob, collections, subprocess

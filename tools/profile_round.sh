@@ -9,11 +9,11 @@ python bench.py --config c2 --steps 50 --warmup 5 > $O/bench_c2.json 2> $O/bench
 python bench.py --config c5 --steps 10 --warmup 3 > $O/bench_c5.json 2> $O/bench_c5.err
 python bench.py --config c4 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_c4_1gpu.json 2> $O/bench_c4.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-modes > $O/stats.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -- python3 $R/bench.py --config c5 --steps 10 --warmup 3 --no-cpu-baseline > $O/stats_c5.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -- python3 $R/bench.py --config c2 --steps 50 --warmup 5 --no-cpu-baseline > $O/stats_c2.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --no-modes > $O/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --no-modes > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-modes --no-live-traffic > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -- python3 $R/bench.py --config c5 --steps 10 --warmup 3 --no-cpu-baseline --no-live-traffic > $O/stats_c5.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -- python3 $R/bench.py --config c2 --steps 50 --warmup 5 --no-cpu-baseline --no-live-traffic > $O/stats_c2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --no-modes --no-live-traffic > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --no-modes --no-live-traffic > $O/pmc_write.log 2>&1
 # calibration of the counters on a kernel with a KNOWN byte count and the same access shape:
 # the staged extractor's k_classify reads the 512 MiB field once with dword loads and writes 16 MiB of sign words
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/cal_fetch -- python3 $R/tools/calibrate_fetch.py > $O/cal_fetch.log 2>&1
