@@ -226,7 +226,7 @@ def measure_traffic_live():
             for tag, ctrs in passes.items():
                 cmd = ["rocprofv3", "--pmc", *ctrs, "--kernel-trace", "--output-format", "csv", "-d", f"{td}/{tag}", "--",
                        sys.executable, str(ROOT / "bench.py"), "--child", "stream", "--steps", "5", "--warmup", "2"]
-                subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=300)
+                subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=120)
                 acc = {}
                 for f in glob.glob(f"{td}/{tag}/**/*counter_collection.csv", recursive=True):
                     for r in csv.DictReader(open(f)):
