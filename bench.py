@@ -170,7 +170,9 @@ def other_configs(p3d, capi, perlin_grid, dev):
 
 def child_exact_mode(steps, warmup):
     """`--child exact` (run by measure_modes in a fresh process with P3D_MC_MODE=exact): the adapter in the reference's own
-    call structure -- count pass, host read of (V, F), exact allocation, emit pass (marching_cubes.cu:242-287)."""
+    call order -- count, host read of (V, F), exact allocation, emit (marching_cubes.cu:242-287).  Since round 4 the field
+    is streamed ONCE for it when the guess for the internal vertex scratch holds (parts 3 / 4 / 6 of the C ABI); the
+    two-pass route (count-only pass, then an exactly sized pass) remains behind it."""
     import torch
     import primitive3d_amd as p3d
     from primitive3d_amd import capi
@@ -246,8 +248,9 @@ def measure_traffic_live():
 def measure_modes(p3d, capi, grid, lower, upper):
     """What a call costs OUTSIDE the steady state the headline measures (same grid, same boundary function; a few steps
     each, after the headline's timed region):
-      exact            P3D_MC_MODE=exact in a fresh child process: count -> read -> exact allocation -> second pass, the
-                       reference's own structure (marching_cubes.cu:242-287)
+      exact            P3D_MC_MODE=exact in a fresh child process: count -> read (V, F) on the host -> exact allocation -> emit,
+                       the reference's own order (marching_cubes.cu:242-287): freshly allocated tensors of exactly V / F
+                       rows, two host round trips inside the call, one pass over the field
       sparse_dense     the field alternating with an all-outside grid of the same shape (per-frame extraction of a changing
                        field): the adapter sizes its buffers for the largest of the last four calls, so every call is one pass
       hint_miss        one dense call after four sparse ones (the dense size has been forgotten): the field is streamed

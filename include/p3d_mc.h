@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define P3D_MC_ABI_VERSION 7
+#define P3D_MC_ABI_VERSION 8
 
 /* dtype of the scalar field */
 #define P3D_F32 0
@@ -72,7 +72,13 @@ typedef struct p3d_mc_slab {
                                 5: faces (with the halo plane's imported records and the id bases) and the rest of
                                    the vertex compaction in one launch -- what parts 0/2 do for a slab without a
                                    halo plane.  (After parts 0/2 with a halo plane p3d_mc_emit writes the faces.)
-                                All parts of one extraction must be given the same buffers and stream. */
+                                6: like 5, but with the WHOLE vertex compaction: for a caller that gave part 4 no vertex
+                                   buffer (vertices = NULL, cap_vertices = 0) because it sizes its outputs from the totals
+                                   part 4 reports -- stream once (part 3, split_plane 0), count (part 4), read V and F,
+                                   allocate exactly, emit (part 6): the reference's count -> allocate -> emit order
+                                   (marching_cubes.cu:242-287) with ONE pass over the field.
+                                All parts of one extraction must be given the same buffers and stream (the output buffers
+                                from the part on that first uses them). */
     int64_t vertex_id_base;      /* added to every locally owned vertex id written into faces */
     int64_t halo_vertex_id_base; /* added to the imported records of the halo plane */
     int64_t x_origin;            /* global axis-0 index of local plane 0: vertex x = float(x_origin + x) + dt */

@@ -134,7 +134,7 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     const CapKey key{dev.index(), rx, ry, rz};
     int64_t capv = 0, capf = 0;
     int slack_q = 5;
-    if (!exact_mode) {
+    {
         std::lock_guard<std::mutex> g(g_cap_mu);
         auto it = g_cap_hint.find(key);
         if (it != g_cap_hint.end()) {
@@ -146,7 +146,42 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
             capf = 2 * capv;
         }
     }
-    bool ok = run_pass(capv, capf, slack_q, 4);
+    // P3D_MC_MODE=exact: the reference's order -- count, read (V, F), allocate exactly, emit (marching_cubes.cu:242-287) --
+    // with ONE pass over the field when the guess holds for the vertex SCRATCH (the only thing sized by it here): the field
+    // is streamed into the scratch regions (part 3), the faces are counted (part 4), the host reads the totals, allocates
+    // the two tensors and the face launch writes into them (part 6).  A scratch region that overflowed, or ids beyond a
+    // region's range: the two-pass route below (count-only pass, then an exactly sized pass).
+    bool exact_done = false;
+    if (exact_mode) {
+        const int64_t per_region = (capv + 31) / 32;
+        const int64_t scratch_rows = 32 * std::max<int64_t>(per_region * slack_q / 4 + 256, std::min<int64_t>(capv, 8192));
+        Tensor scratch = torch::empty({scratch_rows, 3}, vopt);
+        p3d_mc_slab parts{};
+        parts.part = 3;
+        auto call = [&](float* v, int64_t cv, int32_t* f, int64_t cf) {
+            check_rc(p3d_mc_extract_fused(grid, P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, &parts,
+                                          ws.data_ptr(), v, cv, scratch.data_ptr<float>(), scratch_rows, f, cf, stream),
+                     "p3d_mc_extract_fused");
+        };
+        call(nullptr, 0, nullptr, 0);
+        parts.part = 4;
+        call(nullptr, 0, nullptr, 0);
+        int32_t overflow = 0;
+        check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, &overflow, stream), "p3d_mc_read_counts");
+        region_overflow = (overflow & 1) != 0;
+        id_overflow = (overflow & 2) != 0;
+        if (!overflow) {
+            vertices = torch::empty({nv, 3}, vopt);
+            faces = torch::empty({nf, 3}, fopt);
+            if (nv > 0) {
+                parts.part = 6;
+                call(vertices.data_ptr<float>(), nv, nf ? faces.data_ptr<int32_t>() : nullptr, nf);
+            }
+            exact_done = true;
+        }
+    }
+    // (exact mode whose scratch guess did not hold: the counts are right all the same -- straight to the exactly sized pass)
+    bool ok = exact_done || (!exact_mode && run_pass(capv, capf, slack_q, 4));
     {
         // a field whose vertices are spread unevenly over the 32 regions gets more headroom per region next time
         std::lock_guard<std::mutex> g(g_cap_mu);
@@ -168,6 +203,7 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
                 t_prev_out ? t_in - t_prev_out : 0.0, t_sync - t_in, (int)ok);
         t_prev_out = t_sync;
     }
+    if (exact_done) return {vertices, faces};
     if (!ok || exact_mode) {
         const int64_t ev = nv, ef = nf;  // exact sizes are known now
         ok = !id_overflow && run_pass(ev, ef, std::max(8, 2 * slack_q), 4);

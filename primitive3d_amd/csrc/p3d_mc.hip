@@ -1994,7 +1994,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     const int part = slab ? slab->part : 0;
     // parts (p3d_mc_slab.part): 0 everything; 1 planes [0, split) only; 2 planes [split, rx) + finalize;
     // 3 planes [split, rx) + early header, no finalize; 4 face count (+ first slices of the vertex copy), totals to
-    // the host; 5 faces (+ the rest of the vertex copy)
+    // the host; 5 faces (+ the rest of the vertex copy); 6 faces + the WHOLE vertex copy (part 4 was given no vertex buffer)
     int x_lo = 0, x_hi = (int)d.rx;
     if (part == 1) x_hi = (int)slab->split_plane;
     if (part == 2 || part == 3) x_lo = (int)slab->split_plane;
@@ -2037,15 +2037,15 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     // prefixes); the records stay in region form and k_faces makes them dense on the fly.  Without a face buffer, or
     // with a halo plane (its records arrive later: the faces are then written by p3d_mc_emit), the launch consists of
     // those first blocks only.
-    const bool faces_here = w.nb_f > 0 && capf > 0 && (!halo || part == 5);
+    const bool faces_here = w.nb_f > 0 && capf > 0 && (!halo || part >= 5);
     u64 seq = 0;
-    u64* mb = part == 5 ? nullptr : mailbox_open(ws, &seq);
+    u64* mb = part >= 5 ? nullptr : mailbox_open(ws, &seq);
     // the copy of the vertex regions is split over the two launches: `early` of `nparts` slices of every region ride
     // with the counting kernel (VALU-bound, HBM idle), the rest with k_faces
     const bool copy = scratch && capv > 0;
     const int nparts = copy ? std::max(1, tuning().compact_blocks / kRegions) : 1;
-    const int early = (copy && w.nchunks > 0) ? std::min(nparts - 1, tuning().compact_early) : 0;
-    if (w.nchunks > 0 && part != 5) {
+    const int early = (copy && w.nchunks > 0 && part != 6) ? std::min(nparts - 1, tuning().compact_early) : 0;
+    if (w.nchunks > 0 && part < 5) {
         StageTimer tm(ST_FACES_COUNT, st);
         const CompactArgs cpe{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, early * kRegions, 0, nparts, 0,
                               csum, (int)w.nchunks, cursors, id_limit, 1, nullptr};
@@ -2063,7 +2063,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
                          (slab && slab->rank_counts_stride > 0) ? slab->rank_counts_stride : 1, w.tpp, w.xw, (int)w.cpi,
                      csum, cpre, woff, (const u32*)(ws + w.tile_tris), cursors, mb, seq};
     const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, (nparts - early) * kRegions, early,
-                         nparts, part == 5 ? 0 : 1, csum, (int)w.nchunks, cursors, id_limit, 1, nullptr};
+                         nparts, part >= 5 ? 0 : 1, csum, (int)w.nchunks, cursors, id_limit, 1, nullptr};
     StageTimer tm(ST_EMIT_FACES, st);
     launch_faces(d, w, bits, rec, a, cp, hdr, faces, capf, faces_here, st);
     HIP_TRY(hipGetLastError());
@@ -2212,7 +2212,7 @@ int p3d_mc_extract_fused(const void* grid, int dtype, int64_t rx, int64_t ry, in
     if (cap_vertices > 0 && (!vertex_scratch || scratch_rows < kRegions))
         return fail(P3D_EINVAL, "vertex output needs a scratch buffer of at least 32 rows%s");
     if (int rc = check_dims(rx, ry, rz)) return rc;
-    if (slab && (slab->part < 0 || slab->part > 5)) return fail(P3D_EINVAL, "bad slab part%s");
+    if (slab && (slab->part < 0 || slab->part > 6)) return fail(P3D_EINVAL, "bad slab part%s");
     if (slab && (slab->part == 1 || slab->part == 2) && (slab->split_plane < 1 || slab->split_plane >= rx))
         return fail(P3D_EINVAL, "bad split_plane%s");
     if (slab && slab->part == 3 && (slab->split_plane < 0 || slab->split_plane >= rx))
