@@ -86,17 +86,16 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     Tensor vertices, faces;
     int64_t nv = 0, nf = 0;
 
+    // P3D_MC_MODE=exact, or P3D_MC_EXACT_ALLOC=1 (the older name of the same wish): the returned tensors are freshly
+    // allocated and own exactly V / F rows, like the reference's torch::zeros({V,3}) (marching_cubes.cu:260-263), in the
+    // reference's order count -> read -> allocate -> emit (below).  Default: rows [0, V) of a buffer that may be up to
+    // 1/8 + 4096 rows longer, no host round trip inside the call.
     static const bool exact_mode = [] {
         const char* m = std::getenv("P3D_MC_MODE");
-        return m && std::string(m) == "exact";
+        const char* a = std::getenv("P3D_MC_EXACT_ALLOC");
+        return (m && std::string(m) == "exact") || (a && *a && std::string(a) != "0");
     }();
-    // P3D_MC_EXACT_ALLOC=1: the returned tensors always own exactly V / F rows (a copy when the capacity guess was
-    // larger), like the reference's torch::zeros({V,3}) (marching_cubes.cu:260-263).  Default: rows [0, V) of a buffer
-    // that may be up to 1/8 + 4096 rows longer (no copy of 190 MB per 512^3 call).
-    static const bool exact_alloc = [] {
-        const char* m = std::getenv("P3D_MC_EXACT_ALLOC");
-        return m && *m && std::string(m) != "0";
-    }();
+    constexpr bool exact_alloc = false;   // (the default route narrows; an exact request never reaches `fit` below)
     static const bool host_trace = std::getenv("P3D_HOST_TRACE") != nullptr;
     auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_in = host_trace ? now_us() : 0.0;

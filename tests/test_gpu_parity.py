@@ -277,8 +277,7 @@ def test_ply_of_a_device_resident_extraction(gpu, built, tmp_path):
 @pytest.mark.parametrize("env", [{"P3D_MC_MODE": "exact"}, {"P3D_MC_EXACT_ALLOC": "1"}, {}])
 def test_adapter_modes_in_a_fresh_process(gpu, env):
     """The pybind adapter's two switches are read once per process: `P3D_MC_MODE=exact` (the reference's own order: count,
-    read, allocate exactly, emit) and `P3D_MC_EXACT_ALLOC=1` (returned tensors always own exactly V / F
-    rows).  Each must give the oracle's counts on repeated calls; with exact allocations the storage sizes are exact."""
+    read, allocate exactly, emit) and `P3D_MC_EXACT_ALLOC=1` (its older name).  Each must give the oracle's counts on repeated calls; with exact allocations the storage sizes are exact."""
     import os
     import subprocess
     import sys
