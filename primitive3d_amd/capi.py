@@ -188,7 +188,8 @@ def scratch_rows_for(cap_vertices: int) -> int:
 
 def extract_fused_raw(grid, thresh, lower, upper, ws, vertices, faces, slab=None, full_res=None, scratch=None):
     """p3d_mc_extract_fused: one pass over the field, writes at most the capacities of the two buffers.
-    `scratch` ([rows,3] f32) is required when `vertices` is given; allocated here if omitted."""
+    `scratch` ([rows,3] f32) is required when `vertices` is given; allocated here if omitted.  (Parts 3 and 4 of an
+    extraction in several calls -- p3d_mc_slab.part -- take the scratch without a vertex buffer.)"""
     import torch
     if vertices is not None and vertices.shape[0] and scratch is None:
         scratch = torch.empty((scratch_rows_for(vertices.shape[0]), 3), dtype=torch.float32, device=grid.device)
@@ -203,8 +204,8 @@ def extract_fused_raw(grid, thresh, lower, upper, ws, vertices, faces, slab=None
                                           byref(lo), byref(up), byref(fr) if fr is not None else None,
                                           byref(slab) if slab is not None else None, c_void_p(ws.data_ptr()),
                                           c_void_p(vertices.data_ptr()) if capv else None, capv,
-                                          c_void_p(scratch.data_ptr()) if capv else None,
-                                          scratch.shape[0] if capv else 0,
+                                          c_void_p(scratch.data_ptr()) if scratch is not None else None,
+                                          scratch.shape[0] if scratch is not None else 0,
                                           c_void_p(faces.data_ptr()) if capf else None, capf, _stream_ptr(grid)),
                "p3d_mc_extract_fused")
 

@@ -64,6 +64,39 @@ def test_small_cases_fused_match_oracle(gpu, name):
     _assert_same_mesh(hip, ref)
 
 
+@pytest.mark.parametrize("name", ["noise_33x17x200", "noise_5x7x9_box", "sphere32", "all_outside_4x4x4", "noise_9x5x129"])
+def test_count_allocate_emit_over_one_pass_through_the_c_abi(gpu, name):
+    """The reference's order -- count, read (V, F), allocate exactly, emit (marching_cubes.cu:242-287) -- over ONE pass of
+    the field: p3d_mc_extract_fused part 3 (stream into the scratch), part 4 (count the faces, totals to the host), then
+    buffers of exactly V and F rows, part 6 (faces + the whole vertex compaction into them).  include/p3d_mc.h."""
+    from primitive3d_amd import capi
+    from tests.ws_keys import vertex_keys_from_workspace
+    g, thresh, lower, upper = small_cases()[name]
+    t = torch.from_numpy(np.ascontiguousarray(g)).to(gpu).float()
+    ref = oracle_extract(g, thresh, lower, upper)
+    lower = [0.0, 0.0, 0.0] if lower is None else lower
+    upper = [float(n) for n in t.shape] if upper is None else upper
+    ws = torch.empty(capi.workspace_bytes(*t.shape), dtype=torch.uint8, device=gpu)
+    scratch = torch.empty((capi.scratch_rows_for(max(64, ref[0].shape[0])), 3), device=gpu)
+    before = capi.debug_counters()["streaming_passes"]
+    slab = capi.Slab()
+    slab.part = 3
+    capi.extract_fused_raw(t, thresh, lower, upper, ws, None, None, slab=slab, scratch=scratch)
+    slab.part = 4
+    capi.extract_fused_raw(t, thresh, lower, upper, ws, None, None, slab=slab, scratch=scratch)
+    nv, nf, flags = capi.read_counts(ws, with_flags=True)
+    assert (nv, nf) == (ref[0].shape[0], ref[1].shape[0]) and flags == 0
+    v = torch.full((nv, 3), float("nan"), device=gpu)
+    f = torch.full((nf, 3), -1, dtype=torch.int32, device=gpu)
+    if nv:
+        slab.part = 6
+        capi.extract_fused_raw(t, thresh, lower, upper, ws, v, f if nf else None, slab=slab, scratch=scratch)
+    torch.cuda.synchronize()
+    assert capi.debug_counters()["streaming_passes"] - before == 1
+    keys = vertex_keys_from_workspace(ws.cpu().numpy(), t.shape, nv, capi.debug_layout(*t.shape))
+    _assert_same_mesh((v.cpu().numpy(), f.cpu().numpy(), keys), ref)
+
+
 def test_fused_capacity_overflow_falls_back_to_exact_emit(gpu):
     g, thresh, lower, upper = small_cases()["noise_33x17x200"]
     hip = _hip_extract_fused(gpu, g, thresh, lower, upper, cap_vertices=100, cap_faces=50)
