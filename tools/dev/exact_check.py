@@ -1,3 +1,4 @@
+"""dev: the adapter on a few fields incl. degenerate shapes, against the oracle; P3D_MC_MODE=exact also checks the storage sizes.  Ends with the 512^3 call time."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, numpy as np
@@ -8,7 +9,8 @@ from bench import soup_hashes
 from oracle import oracle_extract
 dev = torch.device("cuda", 0)
 for name, g in (("noise", perlin_grid((70, 64, 130), period=16, seed=5, device=dev)), ("sphere", torch.tensor(sphere_grid(96)).float().cuda()),
-                ("empty", torch.ones((40, 40, 70), device=dev)), ("noise2", perlin_grid((200, 190, 260), period=24, seed=2, device=dev))):
+                ("empty", torch.ones((40, 40, 70), device=dev)), ("flat", perlin_grid((1, 50, 130), period=8, seed=3, device=dev)),
+                ("tiny", perlin_grid((2, 2, 2), period=2, seed=1, device=dev)), ("line", perlin_grid((1, 1, 300), period=8, seed=4, device=dev)), ("noise2", perlin_grid((200, 190, 260), period=24, seed=2, device=dev))):
     up = [float(s) for s in g.shape]
     p0 = capi.debug_counters()["streaming_passes"]
     for _ in range(3):
@@ -17,7 +19,8 @@ for name, g in (("noise", perlin_grid((70, 64, 130), period=16, seed=5, device=d
     passes = capi.debug_counters()["streaming_passes"] - p0
     ov, of = oracle_extract(g.cpu().numpy(), 0.0, [0.0] * 3, up)[:2]
     assert v.shape[0] == ov.shape[0] and f.shape[0] == of.shape[0], (name, v.shape, ov.shape)
-    assert v.untyped_storage().nbytes() == max(0, v.shape[0]) * 12 and f.untyped_storage().nbytes() == f.shape[0] * 12, name
+    if os.environ.get("P3D_MC_MODE") == "exact":
+        assert v.untyped_storage().nbytes() == max(0, v.shape[0]) * 12 and f.untyped_storage().nbytes() == f.shape[0] * 12, name
     if f.shape[0]:
         a = soup_hashes(v, f); b = soup_hashes(torch.from_numpy(ov).cuda(), torch.from_numpy(of.astype(np.int32)).cuda())
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), name
