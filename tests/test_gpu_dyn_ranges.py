@@ -106,3 +106,30 @@ def test_dyn_calls_back_to_back_reuse_cleared_tables(gpu, tuning_env, built):
         v, f = capi.extract_fused(g, 0.0, [0.0] * 3, [float(s) for s in g.shape])
         assert (v.shape[0], f.shape[0]) == want[i & 1], i
     assert _dyn_launches() >= before + 12
+
+
+@pytest.mark.parametrize("knobs", [
+    {"P3D_FUSED_NMID": 0},                                            # big + short slabs only (the taper of rounds 2-3)
+    {"P3D_FUSED_NMID": 3, "P3D_FUSED_XT_MID": 3},                     # a few middle slabs of another length
+    {"P3D_FUSED_NBIG": 2, "P3D_FUSED_XT": 9, "P3D_FUSED_XT_TAIL": 1},  # nearly everything in middle and one-plane slabs
+    {"P3D_FUSED_XT": 16, "P3D_FUSED_XT_MID": 15, "P3D_FUSED_NMID": 2},
+    {"P3D_FUSED_BLOCKS": 100000},                                     # one-plane slabs throughout
+])
+def test_fixed_slab_taper_shapes_agree(gpu, tuning_env, built, knobs):
+    """The fixed-slab launch cuts x into long slabs, a middle level and short slabs (csrc/p3d_mc.hip launch_fused); every
+    split must give the default's mesh (sorted triangle soup of bit patterns) -- slabs only move the block boundaries."""
+    from bench import soup_hashes
+    from primitive3d_amd import capi
+    from primitive3d_amd.fields import perlin_grid
+    g = perlin_grid((300, 100, 200), period=20, seed=9, device=gpu)
+    up = [float(s) for s in g.shape]
+    v0, f0 = capi.extract_fused(g, 0.0, [0.0] * 3, up)
+    torch.cuda.synchronize()
+    want = soup_hashes(v0, f0)
+    for k, val in knobs.items():
+        tuning_env(k, val)
+    v, f = capi.extract_fused(g, 0.0, [0.0] * 3, up)
+    torch.cuda.synchronize()
+    got = soup_hashes(v, f)
+    assert (v.shape[0], f.shape[0]) == (v0.shape[0], f0.shape[0]) and f.shape[0] > 100000
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
