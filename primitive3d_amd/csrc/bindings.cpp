@@ -95,7 +95,6 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
         const char* a = std::getenv("P3D_MC_EXACT_ALLOC");
         return (m && std::string(m) == "exact") || (a && *a && std::string(a) != "0");
     }();
-    constexpr bool exact_alloc = false;   // (the default route narrows; an exact request never reaches `fit` below)
     static const bool host_trace = std::getenv("P3D_HOST_TRACE") != nullptr;
     auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_in = host_trace ? now_us() : 0.0;
@@ -226,10 +225,10 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
         return {vertices, faces};
     }
     // exact-size results: the first V / F rows of the buffers; a copy when the guess was generous (the first call on a
-    // shape) or when exact allocations were asked for
+    // shape).  (Exact allocations -- P3D_MC_MODE=exact -- returned above.)
     auto fit = [&](Tensor& t, int64_t n, int64_t cap) {
         if (n == cap) return;
-        t = (!exact_alloc && 2 * n >= cap) ? t.narrow(0, 0, n) : t.narrow(0, 0, n).clone();
+        t = 2 * n >= cap ? t.narrow(0, 0, n) : t.narrow(0, 0, n).clone();
     };
     fit(vertices, nv, capv);
     fit(faces, nf, capf);
