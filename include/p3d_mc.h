@@ -76,7 +76,11 @@ typedef struct p3d_mc_slab {
                                    buffer (vertices = NULL, cap_vertices = 0) because it sizes its outputs from the totals
                                    part 4 reports -- stream once (part 3, split_plane 0), count (part 4), read V and F,
                                    allocate exactly, emit (part 6): the reference's count -> allocate -> emit order
-                                   (marching_cubes.cu:242-287) with ONE pass over the field.
+                                   (marching_cubes.cu:242-287) with ONE pass over the field.  Part 6 may also follow a
+                                   whole call (part 0 / slab = NULL) on the same workspace and scratch whose output
+                                   buffers were too small while the scratch was not (p3d_mc_read_counts: totals above
+                                   the capacities, bit 0 clear): faces and vertices are written again, into the larger
+                                   buffers, without a second pass over the field.
                                 All parts of one extraction must be given the same buffers and stream (the output buffers
                                 from the part on that first uses them). */
     int64_t vertex_id_base;      /* added to every locally owned vertex id written into faces */
@@ -224,7 +228,8 @@ int p3d_mc_shutdown(void);
  *   out[0] streaming launches with fixed x-slabs        out[1] streaming launches with the dynamic plane hand-out
  *   out[2] streaming passes of p3d_mc_extract_fused[_batched] that wrote or counted a whole grid / stack (part 0 or 2, 3)
  *   out[3] calls of the counting / gather pair p3d_mc_count + p3d_mc_emit
- * Writes min(n, 4) values, returns how many. */
+ *   out[4] emissions that had no streaming pass of their own (p3d_mc_slab.part = 6)
+ * Writes min(n, 5) values, returns how many. */
 int p3d_mc_debug_counters(int64_t* out, int n);
 
 const char* p3d_last_error(void);

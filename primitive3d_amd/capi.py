@@ -156,10 +156,11 @@ def shutdown():
 
 def debug_counters():
     """p3d_mc_debug_counters: what the library has launched since it was loaded."""
-    out = (c_int64 * 4)()
-    n = lib().p3d_mc_debug_counters(out, 4)
-    assert n == 4, n
-    return {"fixed_slab_launches": out[0], "dynamic_launches": out[1], "streaming_passes": out[2], "count_emit_calls": out[3]}
+    out = (c_int64 * 5)()
+    n = lib().p3d_mc_debug_counters(out, 5)
+    assert n == 5, n
+    return {"fixed_slab_launches": out[0], "dynamic_launches": out[1], "streaming_passes": out[2], "count_emit_calls": out[3],
+            "emissions_without_a_pass": out[4]}
 
 
 def reload_tuning():

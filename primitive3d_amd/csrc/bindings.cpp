@@ -102,13 +102,19 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     // One streaming pass into buffers of the given capacities (0,0 = count only).  The vertex scratch is cut into
     // 32 independently filled regions: `slack` is the headroom per region, and every region can hold 8192 rows
     // because a small output may come from very few wave-planes.  Returns true when everything fitted.
-    bool region_overflow = false, id_overflow = false;
-    auto run_pass = [&](int64_t capv, int64_t capf, int64_t slack_num, int64_t slack_den) {
-        Tensor scratch;
-        int64_t scratch_rows = 0;
+    bool region_overflow = false, id_overflow = false, scratch_overflow = false;
+    // The scratch is sized for the LARGER of the expectation and a density guess (a vertex per 16 voxels): it is memory of
+    // this call only, and a field that turns out denser than the last few calls on its shape -- or than the guess of a first
+    // call -- then only outgrows the OUTPUT buffers: the faces and the compaction run again into larger ones (below), the
+    // field is not streamed twice.
+    Tensor scratch;
+    int64_t scratch_rows = 0;
+    auto run_pass = [&](int64_t capv, int64_t capf, int64_t slack_num, int64_t slack_den, bool generous) {
+        scratch_rows = 0;
         if (capv > 0) {
-            const int64_t per_region = (capv + 31) / 32;
-            scratch_rows = 32 * std::max<int64_t>(per_region * slack_num / slack_den + 256, std::min<int64_t>(capv, 8192));
+            const int64_t expect = generous ? std::max<int64_t>(capv, rx * ry * rz / 16) : capv;
+            const int64_t per_region = (expect + 31) / 32;
+            scratch_rows = 32 * std::max<int64_t>(per_region * slack_num / slack_den + 256, std::min<int64_t>(expect, 8192));
             scratch = torch::empty({scratch_rows, 3}, vopt);
             vertices = torch::empty({capv, 3}, vopt);
         }
@@ -120,7 +126,8 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
                  "p3d_mc_extract_fused");
         int32_t overflow = 0;
         check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, &overflow, stream), "p3d_mc_read_counts");
-        region_overflow = (overflow & 1) != 0 && nv <= capv;  // the total fitted, the split over the regions did not
+        scratch_overflow = (overflow & 1) != 0;
+        region_overflow = scratch_overflow && nv <= capv;  // the total fitted, the split over the regions did not
         id_overflow = (overflow & 2) != 0;                     // a region outgrew its id space: renumber (below)
         return nv <= capv && nf <= capf && !overflow;
     };
@@ -179,7 +186,7 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
         }
     }
     // (exact mode whose scratch guess did not hold: the counts are right all the same -- straight to the exactly sized pass)
-    bool ok = exact_done || (!exact_mode && run_pass(capv, capf, slack_q, 4));
+    bool ok = exact_done || (!exact_mode && run_pass(capv, capf, slack_q, 4, true));
     {
         // a field whose vertices are spread unevenly over the 32 regions gets more headroom per region next time
         std::lock_guard<std::mutex> g(g_cap_mu);
@@ -202,9 +209,22 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
         t_prev_out = t_sync;
     }
     if (exact_done) return {vertices, faces};
+    if (!ok && !exact_mode && !scratch_overflow && !id_overflow && nv > 0 && scratch_rows > 0) {
+        // only the output buffers were too small: every vertex is in the scratch, the workspace is complete -- the face
+        // launch and the compaction again, into exactly sized tensors (p3d_mc_slab.part = 6 behind a whole call)
+        vertices = torch::empty({nv, 3}, vopt);
+        faces = torch::empty({nf, 3}, fopt);
+        p3d_mc_slab again{};
+        again.part = 6;
+        check_rc(p3d_mc_extract_fused(grid, P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, &again,
+                                      ws.data_ptr(), vertices.data_ptr<float>(), nv, scratch.data_ptr<float>(), scratch_rows,
+                                      nf ? faces.data_ptr<int32_t>() : nullptr, nf, stream),
+                 "p3d_mc_extract_fused");
+        return {vertices, faces};
+    }
     if (!ok || exact_mode) {
         const int64_t ev = nv, ef = nf;  // exact sizes are known now
-        ok = !id_overflow && run_pass(ev, ef, std::max(8, 2 * slack_q), 4);
+        ok = !id_overflow && run_pass(ev, ef, std::max(8, 2 * slack_q), 4, false);
         if (!ok) {
             // a region numbered more than 2^26 vertices: the one-pass ids are ambiguous -> dense ids by the
             // counting call (include/p3d_mc.h: p3d_mc_read_counts, bit 1)

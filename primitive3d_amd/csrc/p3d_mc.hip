@@ -566,6 +566,10 @@ __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr
             const u64 wrap = __ballot(cur > (u64)c.id_limit);   // a region outgrew its id space: ids are ambiguous
             const u64 flags = (over ? 1ull : 0ull) | (wrap ? 2ull : 0ull);
             if (lane < kRegions) hdr[H_PREFIX + lane] = inc - cur;
+            // (the region counts stay with the workspace: a caller whose OUTPUT buffers turned out too small -- not the scratch --
+            //  can have the faces and the compaction run again into larger ones, p3d_mc_slab.part = 6, without streaming the
+            //  field a second time; the call's cursor block goes back to the stream's ring)
+            if (lane < kRegions && c.nitems <= 1 && c.cursors != hdr + H_CURSORS) hdr[H_CURSORS + lane * kCursorStride] = cur;
             if (lane == kRegions - 1) {
                 hdr[H_V] = inc;
                 hdr[H_FLAGS] = flags;
@@ -1493,8 +1497,9 @@ Tuning read_tuning() {
 }
 Tuning g_tuning;
 std::once_flag g_tuning_once;
-// what has been launched so far (p3d_mc_debug_counters): fixed-slab / dynamic streaming launches, streaming passes, count+emit calls
-std::atomic<int64_t> g_counters[4];
+// what has been launched so far (p3d_mc_debug_counters): fixed-slab / dynamic streaming launches, streaming passes, count+emit calls,
+// emissions without a streaming pass of their own (part 6)
+std::atomic<int64_t> g_counters[5];
 const Tuning& tuning() {
     std::call_once(g_tuning_once, [] { g_tuning = read_tuning(); });
     return g_tuning;
@@ -2058,6 +2063,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         HIP_TRY(hipGetLastError());
         return P3D_OK;
     }
+    if (part == 6) g_counters[4].fetch_add(1, std::memory_order_relaxed);
     const FaceArgs a{1, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
                      slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0,
                          (slab && slab->rank_counts_stride > 0) ? slab->rank_counts_stride : 1, w.tpp, w.xw, (int)w.cpi,
@@ -2348,7 +2354,7 @@ int p3d_mc_shutdown(void) {
 
 int p3d_mc_debug_counters(int64_t* out, int n) {
     if (!out || n < 0) return fail(P3D_EINVAL, "null pointer%s");
-    const int m = std::min(n, 4);
+    const int m = std::min(n, 5);
     for (int i = 0; i < m; ++i) out[i] = g_counters[i].load(std::memory_order_relaxed);
     return m;
 }

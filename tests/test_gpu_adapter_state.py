@@ -16,44 +16,64 @@ pytestmark = pytest.mark.gpu
 
 def _passes():
     from primitive3d_amd import capi
-    return capi.debug_counters()["streaming_passes"]
+    c = capi.debug_counters()
+    return c["streaming_passes"], c["emissions_without_a_pass"]
+
+
+def _call(built, g, upper):
+    p0, e0 = _passes()
+    v, f = built.libPrim3D.marching_cubes(g, 0.0, [0.0] * 3, upper)
+    p1, e1 = _passes()
+    return (v.shape[0], f.shape[0]), (p1 - p0, e1 - e0)
 
 
 def test_alternating_sparse_and_dense_frames_stream_once(gpu, built):
-    """sparse / dense / sparse / dense ... on one shape: from the third call on every call is ONE streaming pass."""
+    """sparse / dense / sparse / dense ... on one shape: EVERY call is one streaming pass.  The first dense frame has nothing
+    but an empty frame to go by for its output buffers -- but the vertex scratch is sized for at least a vertex per 16 voxels,
+    so only the buffers are too small: faces and compaction run a second time (p3d_mc_slab.part = 6), the field is not streamed
+    twice.  From the third call on the buffers fit as well."""
     from primitive3d_amd.fields import perlin_grid
     from tests.test_gpu_configs import torch_counts
     shape = (250, 256, 256)   # (a shape no other test uses: its hints start empty)
-    dense = perlin_grid(shape, period=32, seed=3, device=gpu)
+    dense = perlin_grid(shape, period=64, seed=3, device=gpu)
     sparse = torch.ones(shape, device=gpu)   # all outside: V = F = 0
     want = torch_counts(dense, 0.0)
-    assert want[0] > 100000
+    assert 100000 < want[0] < shape[0] * shape[1] * shape[2] // 16
     upper = [float(s) for s in shape]
     per_call = []
     for i in range(8):
-        g = dense if i & 1 else sparse
-        before = _passes()
-        v, f = built.libPrim3D.marching_cubes(g, 0.0, [0.0] * 3, upper)
-        per_call.append(_passes() - before)
-        assert (v.shape[0], f.shape[0]) == (want if i & 1 else (0, 0)), i
-    assert per_call[1] == 2, per_call        # the first dense frame: nothing but an empty frame to go by
-    assert per_call[2:] == [1] * 6, per_call
+        got, how = _call(built, dense if i & 1 else sparse, upper)
+        per_call.append(how)
+        assert got == (want if i & 1 else (0, 0)), i
+    assert per_call[1] == (1, 1), per_call          # one pass, emitted twice
+    assert per_call[2:] == [(1, 0)] * 6, per_call   # one pass, emitted once
 
 
 def test_dense_size_is_forgotten_after_four_sparse_frames(gpu, built):
     from primitive3d_amd.fields import perlin_grid
     shape = (130, 256, 320)
-    dense = perlin_grid(shape, period=32, seed=4, device=gpu)
+    dense = perlin_grid(shape, period=64, seed=4, device=gpu)
     sparse = torch.ones(shape, device=gpu)
     upper = [float(s) for s in shape]
     seq = [dense, dense, sparse, sparse, sparse, dense, sparse, sparse, sparse, sparse, dense]
-    per_call = []
-    for g in seq:
-        before = _passes()
-        built.libPrim3D.marching_cubes(g, 0.0, [0.0] * 3, upper)
-        per_call.append(_passes() - before)
-    assert per_call[1] == 1 and per_call[5] == 1, per_call   # three sparse frames in between: still remembered
-    assert per_call[10] == 2, per_call                        # four: forgotten (buffers shrink again)
+    per_call = [_call(built, g, upper)[1] for g in seq]
+    assert per_call[1] == (1, 0) and per_call[5] == (1, 0), per_call   # three sparse frames in between: still remembered
+    assert per_call[10] == (1, 1), per_call                              # four: forgotten (buffers shrink again) -> emitted twice
+
+
+def test_a_field_denser_than_the_scratch_is_streamed_twice(gpu, built):
+    """White noise has a vertex on nearly every other edge: far beyond a vertex per 16 voxels.  Its first call overflows the
+    scratch regions as well as the buffers, and only a second pass over the field (into exactly sized buffers) can help."""
+    from tests.test_gpu_configs import torch_counts
+    shape = (60, 64, 130)
+    g = torch.from_numpy(np.random.default_rng(5).standard_normal(shape).astype(np.float32)).to(gpu)
+    want = torch_counts(g, 0.0)
+    assert want[0] > shape[0] * shape[1] * shape[2] // 4
+    upper = [float(s) for s in shape]
+    got, how = _call(built, g, upper)
+    assert got == want and how == (2, 0), (got, how)
+    got, how = _call(built, g, upper)
+    assert got == want and how == (1, 0), (got, how)
 
 
 def _hip():
