@@ -112,7 +112,9 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     auto run_pass = [&](int64_t capv, int64_t capf, int64_t slack_num, int64_t slack_den, bool generous) {
         scratch_rows = 0;
         if (capv > 0) {
-            const int64_t expect = generous ? std::max<int64_t>(capv, rx * ry * rz / 16) : capv;
+            // (P3D_MC_SCRATCH_GUESS=0: the scratch follows the expectation alone -- dev A/B)
+            static const bool guess_on = [] { const char* m = std::getenv("P3D_MC_SCRATCH_GUESS"); return !(m && std::string(m) == "0"); }();
+            const int64_t expect = (generous && guess_on) ? std::max<int64_t>(capv, rx * ry * rz / 16) : capv;
             const int64_t per_region = (expect + 31) / 32;
             scratch_rows = 32 * std::max<int64_t>(per_region * slack_num / slack_den + 256, std::min<int64_t>(expect, 8192));
             scratch = torch::empty({scratch_rows, 3}, vopt);
