@@ -109,15 +109,18 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     // field is not streamed twice.
     Tensor scratch;
     int64_t scratch_rows = 0;
+    auto size_scratch = [&](int64_t capv, int64_t slack_num, int64_t slack_den, bool generous) {
+        // (P3D_MC_SCRATCH_GUESS=0: the scratch follows the expectation alone -- dev A/B)
+        static const bool guess_on = [] { const char* m = std::getenv("P3D_MC_SCRATCH_GUESS"); return !(m && std::string(m) == "0"); }();
+        const int64_t expect = (generous && guess_on) ? std::max<int64_t>(capv, rx * ry * rz / 16) : capv;
+        const int64_t per_region = (expect + 31) / 32;
+        scratch_rows = 32 * std::max<int64_t>(per_region * slack_num / slack_den + 256, std::min<int64_t>(expect, 8192));
+        scratch = torch::empty({scratch_rows, 3}, vopt);
+    };
     auto run_pass = [&](int64_t capv, int64_t capf, int64_t slack_num, int64_t slack_den, bool generous) {
         scratch_rows = 0;
         if (capv > 0) {
-            // (P3D_MC_SCRATCH_GUESS=0: the scratch follows the expectation alone -- dev A/B)
-            static const bool guess_on = [] { const char* m = std::getenv("P3D_MC_SCRATCH_GUESS"); return !(m && std::string(m) == "0"); }();
-            const int64_t expect = (generous && guess_on) ? std::max<int64_t>(capv, rx * ry * rz / 16) : capv;
-            const int64_t per_region = (expect + 31) / 32;
-            scratch_rows = 32 * std::max<int64_t>(per_region * slack_num / slack_den + 256, std::min<int64_t>(expect, 8192));
-            scratch = torch::empty({scratch_rows, 3}, vopt);
+            size_scratch(capv, slack_num, slack_den, generous);
             vertices = torch::empty({capv, 3}, vopt);
         }
         if (capf > 0) faces = torch::empty({capf, 3}, fopt);
@@ -135,9 +138,9 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     };
 
     // Output sizes: the reference counts first (marching_cubes.cu:242-252).  Here the default is to guess them from
-    // the last call on a grid of this shape (first call: a density guess), stream the field ONCE, and only if the
-    // guess was too small stream it a second time into exactly sized buffers.  P3D_MC_MODE=exact always does the
-    // reference's two steps (count pass, then an exactly sized pass).
+    // the last calls on a grid of this shape (first call: a density guess) and to stream the field ONCE; a guess that was
+    // too small costs a second face launch and compaction, or -- when the scratch was too small as well -- a second pass
+    // over the field into exactly sized buffers.  P3D_MC_MODE=exact keeps the reference's order (below).
     const CapKey key{dev.index(), rx, ry, rz};
     int64_t capv = 0, capf = 0;
     int slack_q = 5;
@@ -160,9 +163,7 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     // region's range: the two-pass route below (count-only pass, then an exactly sized pass).
     bool exact_done = false;
     if (exact_mode) {
-        const int64_t per_region = (capv + 31) / 32;
-        const int64_t scratch_rows = 32 * std::max<int64_t>(per_region * slack_q / 4 + 256, std::min<int64_t>(capv, 8192));
-        Tensor scratch = torch::empty({scratch_rows, 3}, vopt);
+        size_scratch(capv, slack_q, 4, true);
         p3d_mc_slab parts{};
         parts.part = 3;
         auto call = [&](float* v, int64_t cv, int32_t* f, int64_t cf) {
@@ -175,7 +176,7 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
         call(nullptr, 0, nullptr, 0);
         int32_t overflow = 0;
         check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, &overflow, stream), "p3d_mc_read_counts");
-        region_overflow = (overflow & 1) != 0;
+        scratch_overflow = region_overflow = (overflow & 1) != 0;
         id_overflow = (overflow & 2) != 0;
         if (!overflow) {
             vertices = torch::empty({nv, 3}, vopt);
