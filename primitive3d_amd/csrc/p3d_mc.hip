@@ -909,6 +909,9 @@ __global__ void k_early_header(u64* __restrict__ hdr, const u64* __restrict__ cu
     const u64 over = __ballot(cur > (u64)rows_per_region);
     const u64 wrap = __ballot(cur > (u64)id_limit);
     if (lane < kRegions) hdr[H_PREFIX + lane] = inc - cur;
+    // (the cursors of a slab streamed in ONE call come from the stream's ring of pre-cleared blocks, like a whole grid's: the
+    //  later parts of the extraction find the region counts in the workspace header)
+    if (lane < kRegions && cursors != hdr + H_CURSORS) hdr[H_CURSORS + lane * kCursorStride] = cur;
     if (lane == kRegions - 1) {
         hdr[H_V] = inc;
         hdr[H_FLAGS] = (over ? 1ull : 0ull) | (wrap ? 2ull : 0ull);
@@ -1474,7 +1477,7 @@ int env_int(const char* name, int dflt) {
 struct Tuning {
     int fused_blocks, fused_xt, fused_xt_tail, fused_tail_div, split_rows, small16, compact_blocks, compact_early,
         test_id_limit, no_chunk_pre, test_index_limit, stack_nparts, stack_early, fused_dyn, dyn_min_planes, fused_nbig, fused_nmid,
-        fused_xt_mid, faces_sparse;
+        fused_xt_mid, faces_sparse, parts_ring;
 };
 Tuning read_tuning() {
     Tuning t = Tuning{env_int("P3D_FUSED_BLOCKS", 2048), env_int("P3D_FUSED_XT", -1), env_int("P3D_FUSED_XT_TAIL", -1),
@@ -1484,7 +1487,7 @@ Tuning read_tuning() {
                   env_int("P3D_TEST_INDEX_LIMIT", 0x7fffffff), env_int("P3D_STACK_NPARTS", -1), env_int("P3D_STACK_EARLY", -1),
                   env_int("P3D_FUSED_DYN", 0), env_int("P3D_FUSED_DYN_MIN_PLANES", 64), env_int("P3D_FUSED_NBIG", -1),
                   env_int("P3D_FUSED_NMID", -1), env_int("P3D_FUSED_XT_MID", -1),
-                  env_int("P3D_FACES_SPARSE", -1)};
+                  env_int("P3D_FACES_SPARSE", -1), env_int("P3D_PARTS_RING", 1)};
     // (knobs that are divided by or used as counts: a zero or negative value from the environment means "the smallest legal")
     t.fused_blocks = std::max(1, t.fused_blocks);
     t.fused_tail_div = std::max(1, t.fused_tail_div);
@@ -2009,7 +2012,10 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     u64 *cursors = nullptr, *zero_next = nullptr;
     RingLease lease;   // (released when this function returns: every launch of the call is enqueued by then)
     const bool new_block = part == 0 || part == 1 || (part == 3 && slab->split_plane == 0);
-    if (part == 0) {
+    // (part 3 from plane 0 streams the whole slab in this one call: a ring block serves it too, and k_early_header leaves the
+    //  region counts in the workspace header for the parts that follow -- no clearing kernel in front of the streaming kernel)
+    const bool ring_block = part == 0 || (part == 3 && slab->split_plane == 0 && tuning().parts_ring != 0);   // (P3D_PARTS_RING=0: dev A/B)
+    if (ring_block) {
         if (int rc = cursor_block_for(st, &lease, &cursors, &zero_next)) return rc;
     } else {
         cursors = hdr + H_CURSORS;
