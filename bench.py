@@ -152,6 +152,12 @@ def other_configs(p3d, capi, perlin_grid, dev):
                        "baseline of the 8-GPU target)",
             lambda: p3d.libPrim3D.marching_cubes(g4, 0.0, [0.0] * 3, [1024.0] * 3), 1024 ** 3, 4, steps=6)
     del g4
+    try:
+        out["c4_rank_slab"] = rank_slab_workload(capi, perlin_grid, dev)
+        out["c4_rank_slab"]["predicted_speedup_8gpu_no_transport"] = round(
+            out["c4_1gpu"]["ms_per_step"] / out["c4_rank_slab"]["ms_per_step"], 2)
+    except Exception as e:   # (the headline must not depend on it)
+        out["c4_rank_slab"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     # SURVEY.md 8d, C3's secondary workload: four octaves (period 64 -> 8, persistence 0.5), about 6.5 % active cells
     g6 = perlin_grid((512,) * 3, period=64, seed=0, octaves=4, persistence=0.5, device=dev)
     measure("c3_4oct", "512x512x512 fp32 four-octave Perlin SDF (periods 64..8, persistence 0.5, seed 0), iso 0",
@@ -165,6 +171,72 @@ def other_configs(p3d, capi, perlin_grid, dev):
             lambda: p3d.libPrim3D.marching_cubes(g7, 0.0, [0.0] * 3, [512.0] * 3), 512 ** 3, 4, steps=20)
     del g7
     torch.cuda.empty_cache()
+    return out
+
+
+def rank_slab_workload(capi, perlin_grid, dev, world=8, rank=3, shape=(1024, 1024, 1024), steps=12, warmup=4):
+    """What ONE rank of the 8-GPU run of BASELINE.json configs[3] does per step, on this GPU: rank 3's slab of the 1024^3
+    volume -- 128 planes + the halo plane -- through SlabExtractor.extract()'s real sequence (interior planes streamed
+    while the halo plane would travel: part 1; the last planes + header: part 3; export of the first plane's records for the
+    previous rank; face count + early vertex copy: part 4; faces with the id bases taken ON THE DEVICE from the gathered
+    counts + the rest of the copy: part 5).  The transport is stubbed: the halo plane and the imported records are local
+    device copies of the right size, the all-gather a device copy of this rank's header words into its row -- so this is the
+    per-rank cost WITHOUT xGMI latency, and c4_1gpu / this = the speed-up the 8-GPU run can reach at most."""
+    import torch
+    import torch.distributed as dist
+    from primitive3d_amd.slab import SlabExtractor
+    ex = SlabExtractor(shape, rank, world, dev)
+    ex.fill_local(lambda x0, x1: perlin_grid(shape, period=64, seed=0, device=dev, x0=x0, x1=x1))
+    halo_src = perlin_grid(shape, period=64, seed=0, device=dev, x0=ex.x1, x1=ex.x1 + 1)[0].contiguous()
+    rec_src = {}
+
+    class _Op:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor = op, tensor
+
+    def _batch(ops):   # a receive = a local copy of as many bytes; a send = nothing (the peer's receive is its copy)
+        for o in ops:
+            if o.op == "recv":
+                if o.tensor.shape == halo_src.shape and o.tensor.dtype == halo_src.dtype:
+                    o.tensor.copy_(halo_src)
+                else:
+                    src = rec_src.setdefault(o.tensor.numel(), torch.zeros(o.tensor.numel(), dtype=o.tensor.dtype, device=dev))
+                    o.tensor.copy_(src)
+        return []
+
+    def _all_gather(out_t, inp):
+        out_t.zero_()   # (the other ranks' rows: their counts would arrive here)
+        out_t.view(world, -1)[rank].copy_(inp.view(-1))
+
+    saved = {k: getattr(dist, k, None) for k in ("get_backend", "P2POp", "batch_isend_irecv", "all_gather_into_tensor", "isend", "irecv")}
+    try:
+        dist.get_backend = lambda *a, **k: "nccl"
+        dist.P2POp, dist.batch_isend_irecv, dist.all_gather_into_tensor = _Op, _batch, _all_gather
+        dist.isend, dist.irecv = "send", "recv"
+        lower, upper = [0.0] * 3, [float(n) for n in shape]
+        # (the other ranks' counts: zeros would do for timing; a made-up base keeps the id arithmetic realistic)
+        for _ in range(warmup):
+            res = ex.extract(0.0, lower, upper)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = ex.extract(0.0, lower, upper)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        ex.trace = True
+        res = ex.extract(0.0, lower, upper)
+        phases = {k: round(v, 4) for k, v in ex.phase_times_ms().items()}
+    finally:
+        for k, v in saved.items():
+            setattr(dist, k, v)
+    nvox = ex.n * shape[1] * shape[2]
+    out = {"workload": f"rank {rank} of {world} of the 1024^3 run: a {ex.n}(+1 halo)x{shape[1]}x{shape[2]} fp32 slab through "
+                       "SlabExtractor.extract() (parts 1/3/4/5, record export, device-side id bases), transport stubbed by "
+                       "local copies of the same size",
+           "steps": steps, "ms_per_step": round(ms, 4), "value": round(nvox / (ms * 1e-3) / 1e6, 1), "unit": "Mvoxels/s",
+           "dtype": "f32", "vertices": int(res.vertices.shape[0]), "faces": int(res.faces.shape[0]),
+           "whole_call_frac": round(nvox * 4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "phases_ms_last_step": phases}
+    del ex, res
     return out
 
 
@@ -206,6 +278,26 @@ def child_stream(steps, warmup):
     torch.cuda.synchronize()
 
 
+def run_child(cmd, timeout, capture=False, **kw):
+    """A child process in its OWN session: on a time-out the whole process group goes (a launcher such as rocprofv3 may
+    have spawned the program instead of exec'ing it; killing only the launcher would leave it on the GPU while the
+    sections that follow are being timed).  stdout is returned when asked for, everything else goes to /dev/null."""
+    import signal
+    import subprocess
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE if capture else subprocess.DEVNULL, stderr=subprocess.DEVNULL, text=True,
+                         start_new_session=True, **kw)
+    try:
+        out, _ = p.communicate(timeout=timeout)
+        return out
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        p.wait()
+        raise
+
+
 def measure_traffic_live():
     """The bytes `k_fused` moves over the fabric per launch, measured in THIS run: two `rocprofv3 --pmc` passes (counters
     only, with --kernel-trace: the combination the GPU pool allows) over a child process that makes the headline's call
@@ -216,7 +308,6 @@ def measure_traffic_live():
     import csv
     import glob
     import shutil
-    import subprocess
     import tempfile
     if not shutil.which("rocprofv3") or any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None   # (not there, or this process is itself being profiled)
@@ -228,7 +319,7 @@ def measure_traffic_live():
             for tag, ctrs in passes.items():
                 cmd = ["rocprofv3", "--pmc", *ctrs, "--kernel-trace", "--output-format", "csv", "-d", f"{td}/{tag}", "--",
                        sys.executable, str(ROOT / "bench.py"), "--child", "stream", "--steps", "5", "--warmup", "2"]
-                subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=120)
+                run_child(cmd, timeout=120, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
                 acc = {}
                 for f in glob.glob(f"{td}/{tag}/**/*counter_collection.csv", recursive=True):
                     for r in csv.DictReader(open(f)):
@@ -245,7 +336,7 @@ def measure_traffic_live():
         return None
 
 
-def measure_modes(p3d, capi, grid, lower, upper):
+def measure_modes(p3d, capi, grid, lower, upper, perlin_grid):
     """What a call costs OUTSIDE the steady state the headline measures (same grid, same boundary function; a few steps
     each, after the headline's timed region):
       exact            P3D_MC_MODE=exact in a fresh child process: count -> read (V, F) on the host -> exact allocation -> emit,
@@ -255,15 +346,22 @@ def measure_modes(p3d, capi, grid, lower, upper):
                        field): the adapter sizes its buffers for the largest of the last four calls, so every call is one pass
       hint_miss        one dense call after four sparse ones (the dense size has been forgotten): the output buffers are too
                        small, the vertex scratch (sized for at least a vertex per 16 voxels) is not -- faces and compaction run
-                       a second time into larger buffers (`emissions_per_call` 2), the field is streamed once"""
-    import subprocess
+                       a second time into larger buffers (`emissions_per_call` 2), the field is streamed once
+      fresh_grid       FOUR distinct 512^3 Perlin grids (seeds 0..3: 2 GiB, eight times the 256 MB memory-side cache) taken in
+                       turn through the same call: the headline re-extracts ONE resident grid, and part of that grid is
+                       still in the memory-side cache when the next call starts (profiles/r04/dyn_ranges.txt section 13:
+                       ~10 us of k_fused); a caller streaming new grids sees this number.  `k_fused_ms` by the same
+                       dispatch-attached events as `roofline` -> `roofline.frac_fresh`
+      two_phase        the literal binding INTEGRATION.md section 2 shows first: p3d_mc_count -> p3d_mc_read_counts -> allocate
+                       -> p3d_mc_emit (the reference's structure, marching_cubes.cu:242-287, kernel for kernel: a
+                       classification pass, scans, then a gather emitter that reads the field a second time)"""
     import torch
     out = {}
     try:
         env = dict(os.environ, P3D_MC_MODE="exact")
-        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--child", "exact", "--steps", "8", "--warmup", "3"],
-                           env=env, capture_output=True, text=True, timeout=600)
-        out["exact"] = json.loads(r.stdout.strip().splitlines()[-1])
+        r = run_child([sys.executable, str(ROOT / "bench.py"), "--child", "exact", "--steps", "8", "--warmup", "3"],
+                      timeout=600, capture=True, env=env)
+        out["exact"] = json.loads(r.strip().splitlines()[-1])
     except Exception as e:   # the headline must not depend on it
         out["exact"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     sparse = torch.ones_like(grid)
@@ -302,6 +400,50 @@ def measure_modes(p3d, capi, grid, lower, upper):
                         "streaming_passes_per_call": sum(n for _, n in miss) / 3, "emissions_per_call": emis / 3,
                         "timing": "synchronised single calls (median of 3)"}
     timed(grid)   # (leave the hints as the headline left them)
+    try:
+        grids = [grid] + [perlin_grid(tuple(grid.shape), period=64, seed=sd, device=grid.device) for sd in (1, 2, 3)]
+        for i in range(8):
+            res = p3d.libPrim3D.marching_cubes(grids[i % 4], 0.0, lower, upper)
+        torch.cuda.synchronize()
+        p0, nst = capi.debug_counters()["streaming_passes"], 16
+        t0 = time.perf_counter()
+        for i in range(nst):
+            res = p3d.libPrim3D.marching_cubes(grids[i % 4], 0.0, lower, upper)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / nst * 1e3
+        passes = (capi.debug_counters()["streaming_passes"] - p0) / nst
+        capi.profile_enable(1)
+        dom = []
+        for i in range(8):
+            res = p3d.libPrim3D.marching_cubes(grids[i % 4], 0.0, lower, upper)
+            dom.append(capi.profile_read().get("k_fused", float("nan")))
+        torch.cuda.synchronize()
+        capi.profile_enable(0)
+        kms = sum(dom) / len(dom)
+        alg = grid.numel() * grid.element_size()
+        out["fresh_grid"] = {"grids": 4, "bytes_rotated": 4 * alg, "steps": nst, "ms_per_step": round(ms, 4),
+                             "k_fused_ms": round(kms, 4), "k_fused_frac": round(alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "whole_call_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "streaming_passes_per_call": passes, "timing": "back-to-back calls between two synchronisations"}
+        del grids, res
+    except Exception as e:
+        out["fresh_grid"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    try:
+        for _ in range(3):
+            v, f = capi.extract(grid, 0.0, lower, upper)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(8):
+            v, f = capi.extract(grid, 0.0, lower, upper)
+        torch.cuda.synchronize()
+        out["two_phase"] = {"ms_per_step": round((time.perf_counter() - t0) / 8 * 1e3, 4), "steps": 8,
+                            "vertices": int(v.shape[0]), "faces": int(f.shape[0]),
+                            "binding": "p3d_mc_count -> p3d_mc_read_counts -> torch.empty x2 -> p3d_mc_emit through ctypes (capi.extract)",
+                            "timing": "back-to-back calls between two synchronisations"}
+        del v, f
+    except Exception as e:
+        out["two_phase"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    timed(grid)
     return out
 
 
@@ -494,10 +636,8 @@ def main():
         traffic = traffic_build = None
         tfile = ROOT / "profiles" / "traffic.json"
         headline = world == 1 and shape == SHAPES[1] and batch == 1 and args.config == "c3"   # this workload only
-        live = measure_traffic_live() if headline and not args.no_live_traffic else None
-        if live:
-            traffic = live["read"] + live["write"]
-        elif tfile.exists() and headline:
+        live = None   # (measured LAST, behind every timed section: it starts child processes -- see below)
+        if tfile.exists() and headline:
             try:
                 tj = json.loads(tfile.read_text())
                 traffic = tj.get("k_fused_hbm_bytes_per_launch")
@@ -508,12 +648,15 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_kernel_ms": round(avg_ms, 4), "launches_timed": len(dom_ms), "timed_on": "the steps right after the timed region (dispatch-attached hipEvents perturb the call stream by ~14 us per call)", "alg_bytes_per_launch": alg_bytes,
                     "whole_call_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        if traffic:   # the same launch time against the bytes the kernel really moves (halo planes and rows, outputs)
-            roofline["traffic_frac"] = round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        def note_traffic():   # the same launch time against the bytes the kernel really moves (halo planes and rows, outputs)
+            if not roofline["traffic"]:
+                return
+            roofline["traffic_frac"] = round(roofline["traffic"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             if live:
                 roofline["traffic_read"], roofline["traffic_write"] = live["read"], live["write"]
                 roofline["traffic_source"] = ("this run: rocprofv3 --pmc over a child making the same call (fabric read requests by "
                                               "request size; WRITE_SIZE), k_fused, mean of the last 3 of 7 launches")
+                roofline.pop("traffic_build", None)
             else:
                 roofline["traffic_source"] = "profiles/traffic.json (a committed PMC result of the build named in traffic_build, not of this run)"
                 roofline["traffic_build"] = traffic_build
@@ -532,12 +675,21 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16" if sizeof == 2 else "f32", "data": "synthetic",
             "config": {"workload": workload,
+                       # which allocation policy of the pybind adapter the headline ran: "hinted"
+                       # (default) or "exact" (P3D_MC_MODE=exact; under `modes` when it is not the headline's)
+                       "adapter_mode": (os.environ.get("P3D_MC_MODE") or "hinted") if world == 1 and batch == 1 else None,
                        "voxels_per_gpu": local_vox, "vertices": nv, "faces": nf,
                        "partition": "none" if world == 1 else f"axis-0 slabs x{world}, 1-plane RCCL halo"},
             "roofline": roofline,
         }
         if world == 1 and args.config == "c3" and not args.size and not args.no_modes:
-            line["modes"] = measure_modes(p3d, capi, grid, lower, upper)
+            line["modes"] = measure_modes(p3d, capi, grid, lower, upper, perlin_grid)
+            fg = line["modes"].get("fresh_grid", {})
+            if "k_fused_frac" in fg:
+                roofline["frac_fresh"] = fg["k_fused_frac"]
+                roofline["frac_note"] = ("frac: the headline re-extracts ONE resident grid (part of it is still in the 256 MB "
+                                         "memory-side cache when the next call starts); frac_fresh: four distinct grids in turn "
+                                         "(modes.fresh_grid)")
         if world == 1 and args.config == "c3" and not args.size and not args.no_other_configs:
             line["other_configs"] = other_configs(p3d, capi, perlin_grid, dev)
         if world == 1 and not args.no_cpu_baseline:
@@ -557,6 +709,12 @@ def main():
                 line["cpu_baseline"] = res
             else:
                 line["cpu_baseline"] = cpu_baseline(grid, thresh, lower, upper, out_v, out_f)
+        # the bytes k_fused really moves, measured in this run -- LAST: two rocprofv3 child processes, after every timed section
+        if headline and not args.no_live_traffic:
+            live = measure_traffic_live()
+            if live:
+                roofline["traffic"] = live["read"] + live["write"]
+        note_traffic()
         print(json.dumps(line))
     if world > 1 and args.stages:
         # per-phase GPU time of the LAST step on every rank (halo wait, all-gather, record exchange, ...): what the first

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define P3D_MC_ABI_VERSION 8
+#define P3D_MC_ABI_VERSION 9
 
 /* dtype of the scalar field */
 #define P3D_F32 0
@@ -81,8 +81,20 @@ typedef struct p3d_mc_slab {
                                    buffers were too small while the scratch was not (p3d_mc_read_counts: totals above
                                    the capacities, bit 0 clear): faces and vertices are written again, into the larger
                                    buffers, without a second pass over the field.
-                                All parts of one extraction must be given the same buffers and stream (the output buffers
-                                from the part on that first uses them). */
+                                All parts of one extraction must be given the same workspace, grid shape, stream and
+                                scratch buffer (the vertex buffer from part 4 on, if part 4 was given one).  The library
+                                CHECKS the order (per workspace; host side, before anything is launched) and returns
+                                P3D_EINVAL with a message for every successor this table does not have:
+                                     call                      legal after (on the same workspace)
+                                     0, 1, 3 with split 0      anything (starts a new extraction)
+                                     2                         1 (same split_plane)
+                                     3 with split_plane > 0    1 (same split_plane)
+                                     4                         3
+                                     5                         4 (the vertex buffer part 4 was given; none if it had none)
+                                     6                         4, or a finished extraction (0, 2, 5, 6)
+                                     p3d_mc_emit               p3d_mc_count, 4, or a finished extraction
+                                (p3d_mc_count and the batched entry also start anew; the state diagram is in
+                                INTEGRATION.md.)  The reference's boundary has no such state: marching_cubes.h:14-15. */
     int64_t vertex_id_base;      /* added to every locally owned vertex id written into faces */
     int64_t halo_vertex_id_base; /* added to the imported records of the halo plane */
     int64_t x_origin;            /* global axis-0 index of local plane 0: vertex x = float(x_origin + x) + dt */
@@ -204,17 +216,29 @@ int p3d_mc_profile_enable(int mode);
 int p3d_mc_profile_read(float* stage_ms, int n);
 const char* p3d_mc_profile_stage_name(int stage);
 
-/* Developer / test hook (no reference counterpart).  The launch-shape knobs of the developer sweeps and the two test
- * hooks (P3D_FUSED_BLOCKS, P3D_FUSED_XT, P3D_FUSED_XT_TAIL, P3D_FUSED_TAIL_DIV, P3D_FUSED_SPLIT_ROWS,
- * P3D_FUSED_SMALL16, P3D_COMPACT_BLOCKS, P3D_COMPACT_EARLY, P3D_STACK_NPARTS, P3D_STACK_EARLY, P3D_TEST_ID_LIMIT,
- * P3D_TEST_INDEX_LIMIT, P3D_NO_CHUNK_PRE, P3D_FUSED_DYN, P3D_FUSED_DYN_MIN_PLANES, P3D_FUSED_NBIG, P3D_FUSED_NMID,
- * P3D_FUSED_XT_MID, P3D_FACES_SPARSE) are read from the environment ONCE, at
- * the first call; this re-reads them.  Not to be called while another thread is inside the library. */
+/* Environment (no reference counterpart: the reference's path reads none).  The library reads SIX variables, once, at its
+ * first call -- every one a supported knob; none changes results, only how the work is launched:
+ *   P3D_FUSED_BLOCKS   (2048)  the streaming launch aims at about this many blocks (x-slabs of at most 16 planes each)
+ *   P3D_FUSED_XT       (rule)  planes per block of the streaming launch, overriding the rule above
+ *   P3D_COMPACT_BLOCKS (256)   blocks that copy the 32 vertex regions to their dense place (a multiple of 32) ...
+ *   P3D_COMPACT_EARLY  (3)     ... of which this many of every 8 ride with the counting launch, the rest with the face launch
+ *   P3D_FACES_SPARSE   (rule)  the face launch's empty-tile pre-check: unset = chosen per launch from the face capacity,
+ *                              0 = never, 1 = always (an object's SDF in a large box whose first call is already sparse)
+ *   P3D_NO_MAILBOX     (0)     1 = p3d_mc_read_counts copies and synchronises instead of polling the pinned mailbox
+ * The pybind adapter (libPrim3D) reads one more, P3D_MC_MODE = hinted (default) | exact.
+ * p3d_mc_reload_tuning re-reads the first five (tests; not to be called while another thread is inside the library).
+ *
+ * Everything else that used to be readable from the environment -- the developer sweeps' launch knobs and the TEST HOOKS
+ * (P3D_TEST_ID_LIMIT, P3D_TEST_INDEX_LIMIT, P3D_TEST_FAIL_AFTER_LEASE, P3D_NO_CHUNK_PRE, P3D_PARTS_RING, P3D_FUSED_XT_TAIL,
+ * ...) -- is compiled in only with -DP3D_DEV_HOOKS=1 (primitive3d_amd/_build.py builds that variant as dev/libp3dmc.so
+ * for the tests that need one).  p3d_mc_dev_hooks() says which variant is loaded: 0 = the default library, in which a
+ * stray P3D_TEST_* in a deployment's environment changes nothing (tests/test_gpu_dev_hooks.py). */
 int p3d_mc_reload_tuning(void);
+int p3d_mc_dev_hooks(void);
 
 /* Library-owned state (no reference counterpart: the reference keeps none, marching_cubes.cu:229-230 allocates its four
  * counters per call).  Per (device, stream) the library keeps a ring of pre-cleared blocks (cursors of the streaming
- * kernel, 0.5 MiB) and per device a 4 KiB pinned mailbox; both are created on first use.
+ * kernel, 16 KiB) and per device a 4 KiB pinned mailbox; both are created on first use.
  *   p3d_mc_release_stream: frees what is kept for `stream` on the CURRENT device, after waiting for the work queued on it.
  *       Call it before destroying a stream the library was used on; a later call on that stream simply creates the state
  *       again.  Unknown streams are fine (returns 0).
@@ -225,11 +249,12 @@ int p3d_mc_shutdown(void);
 
 /* Counters of what the library has launched since it was loaded (no reference counterpart; tests and the bench read them
  * to see which path a call took -- nothing in the data path depends on them):
- *   out[0] streaming launches with fixed x-slabs        out[1] streaming launches with the dynamic plane hand-out
+ *   out[0] streaming launches                            out[1] always 0 (was: launches with the round-4 plane hand-out)
  *   out[2] streaming passes of p3d_mc_extract_fused[_batched] that wrote or counted a whole grid / stack (part 0 or 2, 3)
  *   out[3] calls of the counting / gather pair p3d_mc_count + p3d_mc_emit
  *   out[4] emissions that had no streaming pass of their own (p3d_mc_slab.part = 6)
- * Writes min(n, 5) values, returns how many. */
+ *   out[5] (device, stream) pairs the library currently keeps a cursor ring for (p3d_mc_release_stream / p3d_mc_shutdown)
+ * Writes min(n, 6) values, returns how many. */
 int p3d_mc_debug_counters(int64_t* out, int n);
 
 const char* p3d_last_error(void);

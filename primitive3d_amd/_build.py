@@ -1,7 +1,10 @@
-"""In-tree builds of the two native artefacts (both land next to this file so they travel with the
+"""In-tree builds of the native artefacts (all land next to this file so they travel with the
 repo snapshot):
 
   libp3dmc.so        HIP kernels + C ABI (include/p3d_mc.h), built with hipcc for gfx950
+  dev/libp3dmc.so    the same sources with -DP3D_DEV_HOOKS=1: the developer sweeps' launch knobs and the test hooks
+                     (P3D_TEST_*, P3D_NO_CHUNK_PRE, ...) are compiled in; only tests that need a hook load it
+                     (tests/test_gpu_dev_hooks.py, in a child process with LD_LIBRARY_PATH + P3D_CAPI_LIB)
   libPrim3D*.so      pybind adapter (csrc/bindings.cpp) over that C ABI, built with the host compiler
                      against libtorch; module name kept from the reference (src/pybind/CMakeLists.txt:13-14)
 """
@@ -50,22 +53,45 @@ def capi_path() -> Path:
     return Path(override) if override else PKG / "libp3dmc.so"
 
 
+def capi_dev_path() -> Path:
+    """The -DP3D_DEV_HOOKS=1 variant.  Same file name in its own directory, so that a child process started with
+    LD_LIBRARY_PATH=<that directory> has the pybind module (which links `libp3dmc.so` by name) load it too."""
+    return PKG / "dev" / "libp3dmc.so"
+
+
+def dev_env(base=None) -> dict:
+    """Environment of a child process that runs on the dev-hooks variant (pybind module and ctypes alike)."""
+    env = dict(os.environ if base is None else base)
+    d = str(capi_dev_path().parent)
+    env["LD_LIBRARY_PATH"] = d + (":" + env["LD_LIBRARY_PATH"] if env.get("LD_LIBRARY_PATH") else "")
+    env["P3D_CAPI_LIB"] = str(capi_dev_path())
+    return env
+
+
 def pybind_path() -> Path:
     return PKG / ("libPrim3D" + sysconfig.get_config_var("EXT_SUFFIX"))
 
 
-def build_capi(force: bool = False, verbose: bool = False) -> Path:
-    out = capi_path()
+def build_capi(force: bool = False, verbose: bool = False, dev: bool = False) -> Path:
+    import time
+    out = capi_dev_path() if dev else capi_path()
+    flags = CAPI_EXTRA_FLAGS + (["-DP3D_DEV_HOOKS=1"] if dev else [])
     deps = [CSRC / "p3d_mc.hip", *sorted(CSRC.glob("*.inc")), *sorted(CSRC.glob("*.h")), ROOT / "include" / "p3d_mc.h"]
-    if force or _stale(out, deps, " ".join(CAPI_EXTRA_FLAGS)):
+    if force or _stale(out, deps, " ".join(flags)):
+        out.parent.mkdir(exist_ok=True)
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
                # the reference epilogue is mul-then-add, never an FMA (marching_cubes.cu:298)
-               "-ffp-contract=off", "-Wall", "-Wextra", *CAPI_EXTRA_FLAGS,
+               "-ffp-contract=off", "-Wall", "-Wextra", *flags,
                str(CSRC / "p3d_mc.hip"), "-o", str(out)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
+        t0 = time.time()
         subprocess.check_call(cmd)
-        _write_stamp(out, deps, " ".join(CAPI_EXTRA_FLAGS))
+        dt = time.time() - t0
+        out.with_name(out.name + ".buildtime").write_text(f"{dt:.1f} s  ({' '.join(cmd[:2])} ... p3d_mc.hip)\n")
+        if verbose:
+            print(f"compiled p3d_mc.hip in {dt:.1f} s", file=sys.stderr)
+        _write_stamp(out, deps, " ".join(flags))
     return out
 
 
@@ -133,6 +159,7 @@ def build_rc(force: bool = False, verbose: bool = False) -> Path:
 
 def build_all(force: bool = False, verbose: bool = False):
     a = build_capi(force, verbose)
+    build_capi(force, verbose, dev=True)
     d = build_rc(force, verbose)     # (the pybind adapter links it)
     b = build_pybind(force, verbose)
     c = build_mt(force, verbose)

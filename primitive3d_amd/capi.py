@@ -16,7 +16,7 @@ SYMBOLS = ("p3d_mc_abi_version", "p3d_last_error", "p3d_mc_workspace_bytes", "p3
            "p3d_mc_read_counts", "p3d_mc_emit", "p3d_mc_plane_records", "p3d_mc_export_plane_records", "p3d_mc_profile_enable",
            "p3d_mc_profile_read", "p3d_mc_profile_stage_name", "p3d_mc_extract_fused", "p3d_mc_debug_layout",
            "p3d_mc_workspace_bytes_batched", "p3d_mc_extract_fused_batched", "p3d_mc_reload_tuning",
-           "p3d_mc_debug_counters", "p3d_mc_release_stream", "p3d_mc_shutdown")
+           "p3d_mc_debug_counters", "p3d_mc_release_stream", "p3d_mc_shutdown", "p3d_mc_dev_hooks")
 
 
 class Slab(ctypes.Structure):
@@ -156,11 +156,11 @@ def shutdown():
 
 def debug_counters():
     """p3d_mc_debug_counters: what the library has launched since it was loaded."""
-    out = (c_int64 * 5)()
-    n = lib().p3d_mc_debug_counters(out, 5)
-    assert n == 5, n
-    return {"fixed_slab_launches": out[0], "dynamic_launches": out[1], "streaming_passes": out[2], "count_emit_calls": out[3],
-            "emissions_without_a_pass": out[4]}
+    out = (c_int64 * 6)()
+    n = lib().p3d_mc_debug_counters(out, 6)
+    assert n == 6, n
+    return {"streaming_launches": out[0], "streaming_passes": out[2], "count_emit_calls": out[3],
+            "emissions_without_a_pass": out[4], "stream_rings": out[5]}
 
 
 def reload_tuning():

@@ -10,7 +10,6 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
-#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -39,6 +38,7 @@ constexpr int kHintCalls = 4;
 struct CapHint {
     int64_t nv[kHintCalls] = {0, 0, 0, 0}, nf[kHintCalls] = {0, 0, 0, 0};
     int n = 0;        // calls recorded (the ring's next slot is n % kHintCalls)
+    int64_t peak_v = 0;   // the most vertices any call on this shape produced: bounds the vertex SCRATCH (below)
     int slack_q = 5;  // headroom of every scratch region in quarters (5 = 1.25x); grows after a region overflow
     uint64_t last_use = 0;
     int64_t max_v() const { return *std::max_element(nv, nv + kHintCalls); }
@@ -46,6 +46,7 @@ struct CapHint {
     void record(int64_t v, int64_t f) {
         nv[n % kHintCalls] = v;
         nf[n % kHintCalls] = f;
+        peak_v = std::max(peak_v, v);
         ++n;
     }
 };
@@ -86,33 +87,35 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     Tensor vertices, faces;
     int64_t nv = 0, nf = 0;
 
-    // P3D_MC_MODE=exact, or P3D_MC_EXACT_ALLOC=1 (the older name of the same wish): the returned tensors are freshly
-    // allocated and own exactly V / F rows, like the reference's torch::zeros({V,3}) (marching_cubes.cu:260-263), in the
-    // reference's order count -> read -> allocate -> emit (below).  Default: rows [0, V) of a buffer that may be up to
-    // 1/8 + 4096 rows longer, no host round trip inside the call.
+    // P3D_MC_MODE (the one environment variable this module reads; INTEGRATION.md section 2 says why the default is what it is):
+    //   hinted (default)  rows [0, V) / [0, F) of buffers sized from the last calls on this grid shape, which may be up to
+    //                     1/8 + 4096 rows longer; no host round trip inside the call
+    //   exact             freshly allocated tensors that own exactly V / F rows, like the reference's torch::zeros({V,3})
+    //                     (marching_cubes.cu:260-263), in the reference's order count -> read -> allocate -> emit (below);
+    //                     no state is carried from call to call except the vertex-scratch sizing
     static const bool exact_mode = [] {
         const char* m = std::getenv("P3D_MC_MODE");
-        const char* a = std::getenv("P3D_MC_EXACT_ALLOC");
-        return (m && std::string(m) == "exact") || (a && *a && std::string(a) != "0");
+        TORCH_CHECK(!m || !*m || std::string(m) == "exact" || std::string(m) == "hinted",
+                    "P3D_MC_MODE must be 'hinted' or 'exact', got '", m, "'");
+        return m && std::string(m) == "exact";
     }();
-    static const bool host_trace = std::getenv("P3D_HOST_TRACE") != nullptr;
-    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t_in = host_trace ? now_us() : 0.0;
 
     // One streaming pass into buffers of the given capacities (0,0 = count only).  The vertex scratch is cut into
     // 32 independently filled regions: `slack` is the headroom per region, and every region can hold 8192 rows
     // because a small output may come from very few wave-planes.  Returns true when everything fitted.
     bool region_overflow = false, id_overflow = false, scratch_overflow = false;
-    // The scratch is sized for the LARGER of the expectation and a density guess (a vertex per 16 voxels): it is memory of
-    // this call only, and a field that turns out denser than the last few calls on its shape -- or than the guess of a first
-    // call -- then only outgrows the OUTPUT buffers: the faces and the compaction run again into larger ones (below), the
-    // field is not streamed twice.
+    // The scratch is sized for the LARGER of the expectation and a guess: it is memory of this call only, and a field that
+    // turns out denser than the last few calls on its shape -- or than the guess of a first call -- then only outgrows the
+    // OUTPUT buffers: the faces and the compaction run again into larger ones (below), the field is not streamed twice.
+    // The guess: a vertex per 16 voxels.  Where that is more than 128 MiB of scratch (grids beyond ~560^3) and the shape has a
+    // history, it follows the history instead: twice the most any call on the shape has produced, at least 128 MiB, never
+    // more than a vertex per 16 voxels -- an object's SDF in a 1024^3 box costs 128 MiB of scratch per call, not 0.8 GB,
+    // and a dense frame after a run of sparse ones still finds room on every grid up to that size.
     Tensor scratch;
     int64_t scratch_rows = 0;
+    int64_t scratch_guess = rx * ry * rz / 16;
     auto size_scratch = [&](int64_t capv, int64_t slack_num, int64_t slack_den, bool generous) {
-        // (P3D_MC_SCRATCH_GUESS=0: the scratch follows the expectation alone -- dev A/B)
-        static const bool guess_on = [] { const char* m = std::getenv("P3D_MC_SCRATCH_GUESS"); return !(m && std::string(m) == "0"); }();
-        const int64_t expect = (generous && guess_on) ? std::max<int64_t>(capv, rx * ry * rz / 16) : capv;
+        const int64_t expect = generous ? std::max<int64_t>(capv, scratch_guess) : capv;
         const int64_t per_region = (expect + 31) / 32;
         scratch_rows = 32 * std::max<int64_t>(per_region * slack_num / slack_den + 256, std::min<int64_t>(expect, 8192));
         scratch = torch::empty({scratch_rows, 3}, vopt);
@@ -151,6 +154,9 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
             capv = it->second.max_v() + it->second.max_v() / 8 + 4096;
             capf = it->second.max_f() + it->second.max_f() / 8 + 4096;
             slack_q = it->second.slack_q;
+            constexpr int64_t kFreeRows = (int64_t(128) << 20) / 12;
+            if (scratch_guess > kFreeRows)
+                scratch_guess = std::min<int64_t>(scratch_guess, std::max<int64_t>(2 * it->second.peak_v + 4096, kFreeRows));
         } else {
             capv = std::max<int64_t>(4096, rx * ry * rz / 16);
             capf = 2 * capv;
@@ -203,13 +209,6 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
         h.record(nv, nf);
         h.slack_q = region_overflow ? std::min(2 * slack_q, 32) : slack_q;
         h.last_use = ++g_cap_clock;
-    }
-    if (host_trace) {
-        static double t_prev_out = 0.0;
-        const double t_sync = now_us();
-        fprintf(stderr, "[p3d host] since-prev-return %.1f  first pass %.1f us (fitted: %d)\n",
-                t_prev_out ? t_in - t_prev_out : 0.0, t_sync - t_in, (int)ok);
-        t_prev_out = t_sync;
     }
     if (exact_done) return {vertices, faces};
     if (!ok && !exact_mode && !scratch_overflow && !id_overflow && nv > 0 && scratch_rows > 0) {

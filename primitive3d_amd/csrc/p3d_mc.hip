@@ -40,7 +40,6 @@
 #include "../../include/p3d_mc.h"
 #include "fastdiv.h"
 #include "half_round.h"
-#include "range_sched.h"
 #include "tri_table_packed.inc"
 
 namespace {
@@ -166,9 +165,8 @@ Ws make_ws(const Dims& d) {
     o = align_up(o + (size_t)(w.nb_f + 1) * 4 * 4, 256);
     w.tile_tris = o;   // triangles of every face tile (an empty tile's block returns at once)
     o = align_up(o + (size_t)(w.nb_f + 1) * 4, 256);
-    w.cur = o;         // a stack of items keeps one block of 32 vertex cursors per item here, and behind them the plane
-                       // hand-out table of its streaming launch (range_sched.h)
-    if (d.stack) o = align_up(o + ((size_t)d.nitems * 32 * 16 + kRsTableWords) * 8, 256);
+    w.cur = o;         // a stack of items keeps one block of 32 vertex cursors per item here
+    if (d.stack) o = align_up(o + (size_t)d.nitems * 32 * 16 * 8, 256);
     w.total = o;
     return w;
 }
@@ -1472,22 +1470,48 @@ int env_int(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
-// Launch-shape knobs of the developer sweeps (tools/dev/*.sh) and two test hooks: the environment is read ONCE, at the
-// first call (no getenv in the per-call host path); -1 = "use the built-in rule".
+// What the library reads from the environment -- ONCE, at the first call (no getenv in the per-call host path).
+//   SUPPORTED KNOBS (documented in include/p3d_mc.h and INTEGRATION.md; every build reads them):
+//     P3D_FUSED_BLOCKS, P3D_FUSED_XT, P3D_COMPACT_BLOCKS, P3D_COMPACT_EARLY, P3D_FACES_SPARSE, P3D_NO_MAILBOX
+//   DEVELOPER SWEEPS AND TEST HOOKS: compiled in only with -DP3D_DEV_HOOKS=1 (primitive3d_amd/_build.py builds that variant
+//   as dev/libp3dmc.so for the tests that need a hook); the default library does not contain their names and uses the
+//   built-in value -- a stray P3D_TEST_ID_LIMIT in a deployment's environment changes nothing.
+#ifndef P3D_DEV_HOOKS
+#define P3D_DEV_HOOKS 0
+#endif
+#if P3D_DEV_HOOKS
+#define P3D_DEV_KNOB(name, dflt) env_int(name, dflt)
+#else
+#define P3D_DEV_KNOB(name, dflt) (dflt)
+#endif
 struct Tuning {
-    int fused_blocks, fused_xt, fused_xt_tail, fused_tail_div, split_rows, small16, compact_blocks, compact_early,
-        test_id_limit, no_chunk_pre, test_index_limit, stack_nparts, stack_early, fused_dyn, dyn_min_planes, fused_nbig, fused_nmid,
-        fused_xt_mid, faces_sparse, parts_ring;
+    int fused_blocks, fused_xt, compact_blocks, compact_early, faces_sparse;   // supported; -1 = "use the built-in rule"
+    // dev hooks
+    int fused_xt_tail, fused_tail_div, split_rows, small16, test_id_limit, no_chunk_pre, test_index_limit, stack_nparts,
+        stack_early, fused_nbig, fused_nmid, fused_xt_mid, parts_ring, fail_after_lease;
 };
 Tuning read_tuning() {
-    Tuning t = Tuning{env_int("P3D_FUSED_BLOCKS", 2048), env_int("P3D_FUSED_XT", -1), env_int("P3D_FUSED_XT_TAIL", -1),
-                  env_int("P3D_FUSED_TAIL_DIV", 4), env_int("P3D_FUSED_SPLIT_ROWS", 1), env_int("P3D_FUSED_SMALL16", 1),
-                  env_int("P3D_COMPACT_BLOCKS", 256), env_int("P3D_COMPACT_EARLY", 3),
-                  env_int("P3D_TEST_ID_LIMIT", 1 << 26), env_int("P3D_NO_CHUNK_PRE", 0),
-                  env_int("P3D_TEST_INDEX_LIMIT", 0x7fffffff), env_int("P3D_STACK_NPARTS", -1), env_int("P3D_STACK_EARLY", -1),
-                  env_int("P3D_FUSED_DYN", 0), env_int("P3D_FUSED_DYN_MIN_PLANES", 64), env_int("P3D_FUSED_NBIG", -1),
-                  env_int("P3D_FUSED_NMID", -1), env_int("P3D_FUSED_XT_MID", -1),
-                  env_int("P3D_FACES_SPARSE", -1), env_int("P3D_PARTS_RING", 1)};
+    Tuning t{};
+    t.fused_blocks = env_int("P3D_FUSED_BLOCKS", 2048);     // streaming launch: about this many blocks (x-slabs of <= 16 planes)
+    t.fused_xt = env_int("P3D_FUSED_XT", -1);               // streaming launch: planes per block
+    t.compact_blocks = env_int("P3D_COMPACT_BLOCKS", 256);  // blocks that copy the vertex regions to their dense place
+    t.compact_early = env_int("P3D_COMPACT_EARLY", 3);      // ... of which this many slices ride with the counting launch
+    t.faces_sparse = env_int("P3D_FACES_SPARSE", -1);       // empty-tile pre-check of the face launch: -1 by rule, 0 never, 1 always
+    t.fused_xt_tail = P3D_DEV_KNOB("P3D_FUSED_XT_TAIL", -1);
+    t.fused_tail_div = P3D_DEV_KNOB("P3D_FUSED_TAIL_DIV", 4);
+    t.split_rows = P3D_DEV_KNOB("P3D_FUSED_SPLIT_ROWS", 1);
+    t.small16 = P3D_DEV_KNOB("P3D_FUSED_SMALL16", 1);
+    t.test_id_limit = P3D_DEV_KNOB("P3D_TEST_ID_LIMIT", 1 << 26);           // pretend a region's id space is smaller
+    t.no_chunk_pre = P3D_DEV_KNOB("P3D_NO_CHUNK_PRE", 0);                   // every face tile adds the chunk totals up itself
+    t.test_index_limit = P3D_DEV_KNOB("P3D_TEST_INDEX_LIMIT", 0x7fffffff);  // pretend the int32 limit is smaller
+    t.stack_nparts = P3D_DEV_KNOB("P3D_STACK_NPARTS", -1);
+    t.stack_early = P3D_DEV_KNOB("P3D_STACK_EARLY", -1);
+    t.fused_nbig = P3D_DEV_KNOB("P3D_FUSED_NBIG", -1);
+    t.fused_nmid = P3D_DEV_KNOB("P3D_FUSED_NMID", -1);
+    t.fused_xt_mid = P3D_DEV_KNOB("P3D_FUSED_XT_MID", -1);
+    t.parts_ring = P3D_DEV_KNOB("P3D_PARTS_RING", 1);
+    t.fail_after_lease = P3D_DEV_KNOB("P3D_TEST_FAIL_AFTER_LEASE", 0);      // fail this many whole-grid calls between taking
+                                                                            // their cursor block and their first launch
     // (knobs that are divided by or used as counts: a zero or negative value from the environment means "the smallest legal")
     t.fused_blocks = std::max(1, t.fused_blocks);
     t.fused_tail_div = std::max(1, t.fused_tail_div);
@@ -1495,16 +1519,24 @@ Tuning read_tuning() {
     t.compact_early = std::max(0, t.compact_early);
     t.test_id_limit = std::max(1, t.test_id_limit);
     t.test_index_limit = std::max(1, t.test_index_limit);
-    t.dyn_min_planes = std::max(2, t.dyn_min_planes);
     return t;
 }
 Tuning g_tuning;
 std::once_flag g_tuning_once;
+#if P3D_DEV_HOOKS
+std::atomic<int> g_fail_after_lease{0};
+#endif
 // what has been launched so far (p3d_mc_debug_counters): fixed-slab / dynamic streaming launches, streaming passes, count+emit calls,
 // emissions without a streaming pass of their own (part 6)
 std::atomic<int64_t> g_counters[5];
+void apply_tuning(const Tuning& t) {
+    g_tuning = t;
+#if P3D_DEV_HOOKS
+    g_fail_after_lease.store(t.fail_after_lease);
+#endif
+}
 const Tuning& tuning() {
-    std::call_once(g_tuning_once, [] { g_tuning = read_tuning(); });
+    std::call_once(g_tuning_once, [] { apply_tuning(read_tuning()); });
     return g_tuning;
 }
 
@@ -1515,7 +1547,7 @@ const Tuning& tuning() {
 // kCursorRing - 1 calls earlier on the same stream (stream order makes that safe).  A slab streamed in two parts
 // keeps its block for the second part.
 constexpr int kCursorRing = 4;
-constexpr int kRingSlotWords = kCursorBlockWords + kRsTableWords;   // 32 cursors, then the plane hand-out table (range_sched.h)
+constexpr int kRingSlotWords = kCursorBlockWords;   // the 32 cursors of one call
 struct CursorRing {
     int dev = -1;
     hipStream_t stream = nullptr;
@@ -1536,9 +1568,16 @@ std::map<std::pair<int, hipStream_t>, std::shared_ptr<CursorRing>> g_rings;
 struct RingLease {
     std::shared_ptr<CursorRing> ring;
     std::unique_lock<std::mutex> lock;
+    int next = 0;
+    // The ring moves on only when the call's streaming kernel IS enqueued: that kernel is what dirties the call's block and
+    // clears the next one.  A call that fails between taking its block and that launch (a HIP error, the dev-build hook
+    // P3D_TEST_FAIL_AFTER_LEASE) leaves the ring where it was: the next call takes the same, still clean block, and the
+    // block after it is still waiting for a clearing kernel that will now be that call's.
+    void commit() { if (ring) ring->cur = next; }
 };
 
-// advance: take the next block (and return the one after it in *zero_next, to be cleared by this call's kernel)
+// the next block of the stream's ring (and the one after it in *zero_next, to be cleared by this call's kernel); the caller
+// commits the lease once its streaming kernel is enqueued
 int cursor_block_for(hipStream_t st, RingLease* lease, u64** block, u64** zero_next) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
@@ -1566,9 +1605,9 @@ int cursor_block_for(hipStream_t st, RingLease* lease, u64** block, u64** zero_n
     lease->ring = r;
     lease->lock = std::unique_lock<std::mutex>(r->mu);
     if (!r->base) return fail(P3D_EINVAL, "the stream's state was released while a call on it was starting%s");
-    r->cur = (r->cur + 1) % kCursorRing;
-    *block = r->base + (size_t)r->cur * kRingSlotWords;
-    *zero_next = r->base + (size_t)((r->cur + 1) % kCursorRing) * kRingSlotWords;
+    lease->next = (r->cur + 1) % kCursorRing;
+    *block = r->base + (size_t)lease->next * kRingSlotWords;
+    *zero_next = r->base + (size_t)((lease->next + 1) % kCursorRing) * kRingSlotWords;
     return P3D_OK;
 }
 
@@ -1792,30 +1831,11 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
 }
 
 
-// blocks of the DYN streaming kernel the device holds at once (per variant and device; 0 = not asked yet)
 template <typename T, int NC, int RY>
-int fused_resident_blocks() {
-    static int cached[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    if (cached[dev] == 0) {
-        int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fused<T, NC, RY, true>, kFusedBlock, 0) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
-            (void)hipGetLastError();
-            cached[dev] = -1;
-        } else {
-            cached[dev] = std::max(1, per_cu * cus);
-        }
-    }
-    return cached[dev] > 0 ? cached[dev] : 0;
-}
-
-template <typename T, int NC, int RY, bool kHasDyn>
 void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xform& t, int64_t x_origin, u64* bits,
                   uint2* rec, u64* cursors, u64* zero_next, float* scratch, u32 region_rows, u32 store_rows, int x_lo,
                   int x_hi,
-                  hipEvent_t ev0, hipEvent_t ev1, hipStream_t st, u64* rs_table, int cz_base = 0, int cz_count = -1) {
+                  hipEvent_t ev0, hipEvent_t ev1, hipStream_t st, int cz_base = 0, int cz_count = -1) {
     FusedGeom g;
     g.x_lo = x_lo;
     g.x_hi = x_hi;
@@ -1834,37 +1854,6 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
     const int64_t per_slab = (int64_t)g.nzt * g.nyt * (stack ? d.nitems : 1);
     const Tuning& tn = tuning();
     const u32 thresh16 = half_round_down(thresh);
-    // ---- DYN: persistent blocks, planes handed out dynamically (range_sched.h) -- OFF by default.  Measured
-    // (profiles/r04/dyn_ranges.txt): the hand-out cuts the x-halo re-reads (512^3: 689 -> 600 MB read per launch) but not the
-    // time: a block that runs dry pays ~8 us to find, take and prime a stolen range, and the end of the launch is a few
-    // in-hand planes per block either way.  512^3: 114-122 us against 116-117 with the fixed slabs; 1024^3: -8 % on one box,
-    // +5 % on another; stacks of small grids and mid-size grids lose 5-14 %.
-    // P3D_FUSED_DYN: 0 never (default), 1 single grids whose blocks get ranges of >= P3D_FUSED_DYN_MIN_PLANES (64) planes,
-    // 2 wherever it is possible (>= 2 planes per block; the parity tests), 3 like 2 with P3D_FUSED_BLOCKS blocks (dev sweeps).
-    if constexpr (kHasDyn) {
-        if (rs_table && tn.fused_dyn > 0) {
-            int nb = std::min(fused_resident_blocks<T, NC, RY>(), kRsMaxBlocks);
-            if (tn.fused_blocks > 0 && tn.fused_blocks < nb && tn.fused_dyn > 2) nb = tn.fused_blocks;   // (dev sweeps: P3D_FUSED_DYN=3)
-            nb -= nb % 8;
-            if (nb >= 8 && per_slab <= nb && per_slab < (1 << kRsColBits) && nplanes < (1ll << kRsBits) &&
-                per_slab * nplanes >= (int64_t)nb * (tn.fused_dyn > 1 ? 2 : std::max(2, tn.dyn_min_planes)) && (!stack || tn.fused_dyn > 1)) {
-                g.XT = g.XT_tail = 1;
-                g.n_big = g.nxt = 0;
-                if (stack) g.nxt_item = 1;   // (marks a stack: the item is the tile column's third coordinate)
-                const RsGeom rs = rs_make_geom((u32)nb, (u32)per_slab, (u32)nplanes);
-                g_counters[1].fetch_add(1, std::memory_order_relaxed);
-                if (ev0 || ev1)
-                    hipExtLaunchKernelGGL((k_fused<T, NC, RY, true>), dim3((u32)nb), dim3(kFusedBlock), 0, st, ev0, ev1, 0, grid,
-                                          thresh, thresh16, d, g, halo, t, x_origin, bits, rec, cursors, zero_next, scratch,
-                                          region_rows, store_rows, rs, rs_table);
-                else
-                    hipLaunchKernelGGL((k_fused<T, NC, RY, true>), dim3((u32)nb), dim3(kFusedBlock), 0, st, grid, thresh,
-                                       thresh16, d, g, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                       store_rows, rs, rs_table);
-                return;
-            }
-        }
-    }
     // ---- fixed x-slabs
     // (measured, tools/dev/xt_sweep*.sh / blocks_sweep.sh: about 2000 blocks and at most 16 planes per block -- 12 planes
     //  at 512^3 (120 us vs 124 with 8), 16 at 1024^3 (976 us vs 1140 with the 43 an uncapped rule gave))
@@ -1908,43 +1897,40 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
         g.n_mid = 0;
     }
     const int64_t nblocks = per_slab * g.nxt;
-    const RsGeom rs0 = rs_make_geom(1, 1, 1);
     g_counters[0].fetch_add(1, std::memory_order_relaxed);
     // (the timing events, if any, ride on the dispatch packet itself: no extra barrier packets around the kernel)
     if (ev0 || ev1)   // (rows split over two launches: the first carries the start event, the second the stop event)
-        hipExtLaunchKernelGGL((k_fused<T, NC, RY, false>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, ev0, ev1, 0, grid, thresh,
+        hipExtLaunchKernelGGL((k_fused<T, NC, RY>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, ev0, ev1, 0, grid, thresh,
                               thresh16, d, g, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                              store_rows, rs0, (u64*)nullptr);
+                              store_rows);
     else
-        hipLaunchKernelGGL((k_fused<T, NC, RY, false>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, grid, thresh, thresh16, d, g,
-                           halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows, store_rows, rs0,
-                           (u64*)nullptr);
+        hipLaunchKernelGGL((k_fused<T, NC, RY>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, grid, thresh, thresh16, d, g,
+                           halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows, store_rows);
 }
 
 template <typename T>
 void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xform& t, int64_t x_origin, u64* bits,
                     uint2* rec, u64* cursors, u64* zero_next, float* scratch, u32 region_rows, u32 store_rows, int x_lo,
                   int x_hi,
-                    hipEvent_t ev0, hipEvent_t ev1, hipStream_t st, u64* rs_table) {
+                    hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
     // tile geometries (32 unit words per wave-plane unless noted): long rows (8 chunks x 3 rows per wave), rows of 3-4
     // chunks (rz <= 256: 4 chunks x 6 rows -- the 8-chunk tile would be half empty -- or, for a single small grid,
-    // 16-unit tiles of 4 chunks x 3 rows), short rows (2 chunks x 15 rows).  The plane hand-out table (DYN) serves ONE
-    // launch: rows split over two launches keep their fixed slabs.
+    // 16-unit tiles of 4 chunks x 3 rows), short rows (2 chunks x 15 rows).
     const int rem = (int)(d.ncz % 8);
     if (d.ncz >= 9 && rem >= 1 && rem <= 2 && tuning().split_rows) {
         // rows of 8k + 1..2 chunks (rz = 513, 517, 600, 1025: grids of 2^n + 1 samples are common): the 8-chunk tiles take
         // the first 8k chunks, a second launch with the 2-chunk tile the rest -- a last 8-chunk tile would be 1/8 or 1/4
         // full (513 x 511 x 517: 169 -> 155 us; with 3..4 chunks left over the split measured no gain)
         const int full = (int)d.ncz - rem;
-        launch_fused<T, 8, 3, false>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                     store_rows, x_lo, x_hi, ev0, nullptr, st, nullptr, 0, full);
-        launch_fused<T, 2, 15, false>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                      store_rows, x_lo, x_hi, nullptr, ev1, st, nullptr, full, rem);
+        launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                                     store_rows, x_lo, x_hi, ev0, nullptr, st, 0, full);
+        launch_fused<T, 2, 15>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                                      store_rows, x_lo, x_hi, nullptr, ev1, st, full, rem);
         return;
     }
     if (d.ncz >= 5)
-        launch_fused<T, 8, 3, true>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                    store_rows, x_lo, x_hi, ev0, ev1, st, rs_table);
+        launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                                    store_rows, x_lo, x_hi, ev0, ev1, st);
     else if (d.ncz >= 3 &&
              // (only when 8-plane slabs of the wider-in-y tile still give the chip enough blocks: a single small grid is
              //  better off with more, half-empty tiles than with 2-plane slabs)
@@ -1952,19 +1938,19 @@ void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const 
         // (4 x 6 rows, not the 4 x 7 that would fill the 32 unit slots: a wave-plane of 28 units carries ~75 vertices on the
         //  Perlin stacks -- a full batch of 64 and a nearly empty one --, one of 24 units ~64: 32 x 256^3 fp16 342 -> 328 us,
         //  fp32 556 -> 535 us)
-        launch_fused<T, 4, 6, true>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                    store_rows, x_lo, x_hi, ev0, ev1, st, rs_table);
+        launch_fused<T, 4, 6>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                                    store_rows, x_lo, x_hi, ev0, ev1, st);
     else if (d.ncz >= 3 && tuning().small16)
         // a single small grid: 16-unit tiles (4 chunks x 3 rows + halo row) -- twice the waves of the 8-chunk tile, none
         // of them half empty
-        launch_fused<T, 4, 3, false>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                     store_rows, x_lo, x_hi, ev0, ev1, st, nullptr);
+        launch_fused<T, 4, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                                     store_rows, x_lo, x_hi, ev0, ev1, st);
     else if (d.ncz >= 3)
-        launch_fused<T, 8, 3, true>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                    store_rows, x_lo, x_hi, ev0, ev1, st, rs_table);
+        launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                                    store_rows, x_lo, x_hi, ev0, ev1, st);
     else
-        launch_fused<T, 2, 15, false>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                      store_rows, x_lo, x_hi, ev0, ev1, st, nullptr);
+        launch_fused<T, 2, 15>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
+                                      store_rows, x_lo, x_hi, ev0, ev1, st);
 }
 
 Xform make_xform(const Dims& d, const float lower[3], const float upper[3], const int64_t full_res[3]) {
@@ -2017,6 +2003,10 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     const bool ring_block = part == 0 || (part == 3 && slab->split_plane == 0 && tuning().parts_ring != 0);   // (P3D_PARTS_RING=0: dev A/B)
     if (ring_block) {
         if (int rc = cursor_block_for(st, &lease, &cursors, &zero_next)) return rc;
+#if P3D_DEV_HOOKS
+        if (g_fail_after_lease.load() > 0 && g_fail_after_lease.fetch_sub(1) > 0)
+            return fail(P3D_EHIP, "injected failure between the cursor lease and the first launch (P3D_TEST_FAIL_AFTER_LEASE)%s");
+#endif
     } else {
         cursors = hdr + H_CURSORS;
         if (new_block)   // (an ordinary kernel: the runtime's fill path starts late, see fused_stack_impl)
@@ -2030,11 +2020,11 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         if (timed) g_ev_used[stage] = true;
         if (new_block && part != 1) g_ev_used[ST_FUSED_INTERIOR] = false;
         const int64_t xo = slab ? slab->x_origin : 0;
-        // (the plane hand-out table of a whole-grid call: behind the cursors in the call's ring slot, cleared with them by
-        //  the previous call; an extraction in several parts keeps the fixed x-slabs)
         dispatch_fused<T>(grid, d, thresh, halo, t, xo, bits, rec, cursors, zero_next, scratch, region_rows, store_rows, x_lo, x_hi,
-                          timed ? g_ev[stage][0] : nullptr, timed ? g_ev[stage][1] : nullptr, st,
-                          part == 0 ? cursors + kCursorBlockWords : nullptr);
+                          timed ? g_ev[stage][0] : nullptr, timed ? g_ev[stage][1] : nullptr, st);
+        // (a launch that was refused never ran: the ring stays where it was)
+        HIP_TRY(hipGetLastError());
+        lease.commit();
     }
     if (part == 3)
         hipLaunchKernelGGL(k_early_header, dim3(1), dim3(64), 0, st, hdr, cursors, scratch ? store_rows : region_rows,
@@ -2099,7 +2089,7 @@ int fused_stack_impl(const T* grids, const Dims& d, const Ws& w, float thresh, c
     u32* cpre = (w.nchunks > kPreMinChunks && !tuning().no_chunk_pre) ? (u32*)(ws + w.chunk_pre) : nullptr;   // (see fused_impl)
     // (an ordinary kernel, not hipMemsetAsync: the runtime's fill path left the GPU idle for 11 us before it ran)
     {
-        const int64_t nwords = (int64_t)d.nitems * kCursorBlockWords + kRsTableWords;   // (+ the plane hand-out table)
+        const int64_t nwords = (int64_t)d.nitems * kCursorBlockWords;
         hipLaunchKernelGGL(k_zero_words, dim3((u32)((nwords + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, cursors, nwords);
     }
     const u32 region_rows = 1u << 26;
@@ -2111,8 +2101,7 @@ int fused_stack_impl(const T* grids, const Dims& d, const Ws& w, float thresh, c
     if (timed) g_ev_used[ST_FUSED] = true;
     g_ev_used[ST_FUSED_INTERIOR] = false;
     dispatch_fused<T>(grids, d, thresh, 0, t, 0, bits, rec, cursors, nullptr, scratch, region_rows, store_rows, 0, (int)d.rx,
-                      timed ? g_ev[ST_FUSED][0] : nullptr, timed ? g_ev[ST_FUSED][1] : nullptr, st,
-                      cursors + (size_t)d.nitems * kCursorBlockWords);
+                      timed ? g_ev[ST_FUSED][0] : nullptr, timed ? g_ev[ST_FUSED][1] : nullptr, st);
     u64 seq = 0;
     u64* mb = mailbox_open(ws, &seq);
     const bool copy = scratch && capv > 0;
@@ -2146,6 +2135,148 @@ int fused_stack_impl(const T* grids, const Dims& d, const Ws& w, float thresh, c
     return P3D_OK;
 }
 
+// ---- the order of an extraction's calls (p3d_mc_slab.part) ----------------------------------------------------------------
+// The reference's boundary is stateless (marching_cubes.h:14-15); an extraction made of several calls is not, and a part
+// that runs on a workspace its predecessors never prepared reads whatever the header holds.  The library therefore keeps,
+// per (device, workspace pointer), which part it saw last and with which stream / shape / scratch / vertex buffer, and
+// refuses every successor the diagram in INTEGRATION.md does not have, synchronously, with P3D_EINVAL and a message.
+// Host-side only (a phase word on the device could not fail a call without a synchronisation).  A starting part (0, 1, 3
+// with split_plane 0, p3d_mc_count, the batched entry) is always legal and resets the entry, so a workspace address that
+// an allocator hands out again never inherits a verdict; the table holds the kMaxExtractions most recently used workspaces.
+enum Phase { PH_NONE = 0, PH_INTERIOR /* after part 1 */, PH_STREAMED /* after part 3 */, PH_COUNTED /* after part 4 */,
+             PH_DONE /* after part 0, 2, 5, 6 */, PH_COUNT_CALL /* after p3d_mc_count */, PH_STACK /* the batched entry */ };
+const char* const k_phase_names[] = {"nothing", "part 1", "part 3", "part 4", "a finished extraction (part 0, 2, 5 or 6)",
+                                     "p3d_mc_count", "p3d_mc_extract_fused_batched"};
+struct Extraction {
+    int phase = PH_NONE;
+    hipStream_t stream = nullptr;
+    int64_t rx = 0, ry = 0, rz = 0, split = 0;
+    int dtype = 0;
+    const float* scratch = nullptr;
+    int64_t scratch_rows = 0;
+    const float* verts4 = nullptr;   // the vertex buffer part 4 began to fill (null: it copied nothing)
+    int64_t capv4 = 0;
+    uint64_t last_use = 0;
+};
+constexpr size_t kMaxExtractions = 1024;
+std::mutex g_proto_mu;
+std::map<std::pair<int, const void*>, Extraction> g_proto;
+uint64_t g_proto_clock = 0;
+
+struct ProtoCall {   // what one call presents
+    const void* ws;
+    int part;        // 0..6, or -1 p3d_mc_count, -2 p3d_mc_emit, -3 the batched entry
+    hipStream_t stream;
+    int64_t rx, ry, rz, split;
+    int dtype;
+    const float* scratch;
+    int64_t scratch_rows;
+    const float* verts;
+    int64_t capv;
+};
+
+int proto_fail(const char* what, int last_phase) {
+    snprintf(g_err, sizeof(g_err), "illegal order of calls on this workspace: %s (last seen on it: %s)", what,
+             k_phase_names[last_phase]);
+    return P3D_EINVAL;
+}
+
+// validates the call against the workspace's entry; *out = the entry as it will be when the call has succeeded
+int proto_check(const ProtoCall& c, Extraction* out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    Extraction e;
+    {
+        std::lock_guard<std::mutex> g(g_proto_mu);
+        auto it = g_proto.find({dev, c.ws});
+        if (it != g_proto.end()) e = it->second;
+    }
+    const int last = e.phase;
+    const bool start = c.part == 0 || c.part == 1 || (c.part == 3 && c.split == 0) || c.part == -1 || c.part == -3;
+    if (!start) {
+        // every continuation: the same stream and grid shape as the part that started the extraction
+        if (last == PH_NONE || last == PH_STACK) {
+            if (c.part == -2) return proto_fail("p3d_mc_emit needs a p3d_mc_count or a p3d_mc_extract_fused before it", last);
+            return proto_fail("this part continues an extraction, and none is in progress", last);
+        }
+        if (c.stream != e.stream) return proto_fail("all parts of one extraction must be given the same stream", last);
+        if (c.rx != e.rx || c.ry != e.ry || c.rz != e.rz || c.dtype != e.dtype)
+            return proto_fail("all parts of one extraction must be given the same grid shape and dtype", last);
+    }
+    const bool same_scratch = c.scratch == e.scratch && c.scratch_rows == e.scratch_rows;
+    switch (c.part) {
+        case 0: case 1: case -1: case -3: break;
+        case 2:
+            if (last != PH_INTERIOR) return proto_fail("part 2 needs part 1 before it", last);
+            if (c.split != e.split) return proto_fail("part 2 must continue at part 1's split_plane", last);
+            if (!same_scratch) return proto_fail("part 2 must be given part 1's scratch buffer", last);
+            break;
+        case 3:
+            if (c.split != 0) {
+                if (last != PH_INTERIOR) return proto_fail("part 3 with a split_plane needs part 1 before it", last);
+                if (c.split != e.split) return proto_fail("part 3 must continue at part 1's split_plane", last);
+                if (!same_scratch) return proto_fail("part 3 must be given part 1's scratch buffer", last);
+            }
+            break;
+        case 4:
+            if (last != PH_STREAMED) return proto_fail("part 4 needs part 3 before it", last);
+            if (!same_scratch) return proto_fail("part 4 must be given part 3's scratch buffer", last);
+            break;
+        case 5:
+            if (last != PH_COUNTED) return proto_fail("part 5 needs part 4 before it", last);
+            if (!same_scratch) return proto_fail("part 5 must be given part 4's scratch buffer", last);
+            if (e.verts4 ? (c.verts != e.verts4 || c.capv != e.capv4) : c.capv != 0)
+                return proto_fail(e.verts4 ? "part 5 must be given the vertex buffer part 4 began to fill"
+                                           : "part 4 was given no vertex buffer: part 6 writes the vertices, part 5 cannot", last);
+            break;
+        case 6:
+            if (last != PH_COUNTED && last != PH_DONE) return proto_fail("part 6 needs part 4, or a finished extraction, before it", last);
+            if (!same_scratch) return proto_fail("part 6 must be given the scratch buffer the field was streamed into", last);
+            break;
+        case -2:
+            if (last != PH_COUNT_CALL && last != PH_COUNTED && last != PH_DONE)
+                return proto_fail("p3d_mc_emit needs finished counts (p3d_mc_count, part 4 or a whole extraction) before it", last);
+            break;
+        default: return fail(P3D_EINVAL, "bad slab part%s");
+    }
+    if (start) {
+        e = Extraction();
+        e.stream = c.stream;
+        e.rx = c.rx; e.ry = c.ry; e.rz = c.rz; e.dtype = c.dtype; e.split = c.split;
+        e.scratch = c.scratch; e.scratch_rows = c.scratch_rows;
+    }
+    switch (c.part) {
+        case 0: case 2: case 5: case 6: e.phase = PH_DONE; break;
+        case 1: e.phase = PH_INTERIOR; break;
+        case 3: e.phase = PH_STREAMED; break;
+        case 4:
+            e.phase = PH_COUNTED;
+            e.verts4 = (c.scratch && c.capv > 0) ? c.verts : nullptr;
+            e.capv4 = e.verts4 ? c.capv : 0;
+            break;
+        case -1: e.phase = PH_COUNT_CALL; break;
+        case -3: e.phase = PH_STACK; break;
+        default: break;   // (p3d_mc_emit leaves the phase where it is)
+    }
+    *out = e;
+    return P3D_OK;
+}
+
+void proto_commit(const void* ws, const Extraction& e_in) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> g(g_proto_mu);
+    if (g_proto.size() >= kMaxExtractions && g_proto.find({dev, ws}) == g_proto.end()) {
+        auto oldest = g_proto.begin();
+        for (auto it = g_proto.begin(); it != g_proto.end(); ++it)
+            if (it->second.last_use < oldest->second.last_use) oldest = it;
+        g_proto.erase(oldest);
+    }
+    Extraction e = e_in;
+    e.last_use = ++g_proto_clock;
+    g_proto[{dev, ws}] = e;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -2170,9 +2301,13 @@ int p3d_mc_count(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz
     const Dims d = make_dims(rx, ry, rz);
     const Ws w = make_ws(d);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == P3D_F32) return count_impl((const float*)grid, d, w, thresh, slab, (char*)ws, st);
-    if (dtype == P3D_F16) return count_impl((const __half*)grid, d, w, thresh, slab, (char*)ws, st);
-    return fail(P3D_EINVAL, "unknown dtype%s");
+    if (dtype != P3D_F32 && dtype != P3D_F16) return fail(P3D_EINVAL, "unknown dtype%s");
+    Extraction next;
+    if (int rc = proto_check(ProtoCall{ws, -1, st, rx, ry, rz, 0, dtype, nullptr, 0, nullptr, 0}, &next)) return rc;
+    const int rc = dtype == P3D_F32 ? count_impl((const float*)grid, d, w, thresh, slab, (char*)ws, st)
+                                    : count_impl((const __half*)grid, d, w, thresh, slab, (char*)ws, st);
+    if (rc == P3D_OK) proto_commit(ws, next);
+    return rc;
 }
 
 int p3d_mc_read_counts(const void* ws, int64_t* num_vertices, int64_t* num_faces, int32_t* scratch_overflow,
@@ -2204,13 +2339,14 @@ int p3d_mc_emit(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz,
     const Ws w = make_ws(d);
     const Xform t = make_xform(d, lower, upper, full_res);
     hipStream_t st = (hipStream_t)stream;
+    if (dtype != P3D_F32 && dtype != P3D_F16) return fail(P3D_EINVAL, "unknown dtype%s");
+    Extraction next;
+    if (int rc = proto_check(ProtoCall{ws, -2, st, rx, ry, rz, 0, dtype, nullptr, 0, nullptr, 0}, &next)) return rc;
     if (dtype == P3D_F32)
         return emit_impl((const float*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices, faces,
                          cap_faces, vertex_keys, st);
-    if (dtype == P3D_F16)
-        return emit_impl((const __half*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices, faces,
-                         cap_faces, vertex_keys, st);
-    return fail(P3D_EINVAL, "unknown dtype%s");
+    return emit_impl((const __half*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices, faces,
+                     cap_faces, vertex_keys, st);
 }
 
 int p3d_mc_extract_fused(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz, float thresh,
@@ -2233,13 +2369,18 @@ int p3d_mc_extract_fused(const void* grid, int dtype, int64_t rx, int64_t ry, in
     const Ws w = make_ws(d);
     const Xform t = make_xform(d, lower, upper, full_res);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == P3D_F32)
-        return fused_impl((const float*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices, vertex_scratch,
-                          scratch_rows, faces, cap_faces, st);
-    if (dtype == P3D_F16)
-        return fused_impl((const __half*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices,
-                          vertex_scratch, scratch_rows, faces, cap_faces, st);
-    return fail(P3D_EINVAL, "unknown dtype%s");
+    if (dtype != P3D_F32 && dtype != P3D_F16) return fail(P3D_EINVAL, "unknown dtype%s");
+    Extraction next;
+    if (int rc = proto_check(ProtoCall{ws, slab ? slab->part : 0, st, rx, ry, rz, slab ? slab->split_plane : 0, dtype,
+                                       vertex_scratch, vertex_scratch ? scratch_rows : 0, vertices, cap_vertices}, &next))
+        return rc;
+    const int rc = dtype == P3D_F32
+                       ? fused_impl((const float*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices, vertex_scratch,
+                                    scratch_rows, faces, cap_faces, st)
+                       : fused_impl((const __half*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices,
+                                    vertex_scratch, scratch_rows, faces, cap_faces, st);
+    if (rc == P3D_OK) proto_commit(ws, next);
+    return rc;
 }
 
 int p3d_mc_workspace_bytes_batched(int64_t nitems, int64_t rx, int64_t ry, int64_t rz, size_t* bytes) {
@@ -2267,13 +2408,16 @@ int p3d_mc_extract_fused_batched(const void* grids, int dtype, int64_t nitems, i
     const Dims d1 = make_dims(rx, ry, rz);   // the box transform is the single grid's (marching_cubes.cu:293-297)
     const Xform t = make_xform(d1, lower, upper, nullptr);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == P3D_F32)
-        return fused_stack_impl((const float*)grids, d, w, thresh, t, (char*)ws, vertices, cap_vertices, vertex_scratch,
-                                scratch_rows, faces, cap_faces, item_offsets, st);
-    if (dtype == P3D_F16)
-        return fused_stack_impl((const __half*)grids, d, w, thresh, t, (char*)ws, vertices, cap_vertices,
-                                vertex_scratch, scratch_rows, faces, cap_faces, item_offsets, st);
-    return fail(P3D_EINVAL, "unknown dtype%s");
+    if (dtype != P3D_F32 && dtype != P3D_F16) return fail(P3D_EINVAL, "unknown dtype%s");
+    Extraction next;
+    if (int rc = proto_check(ProtoCall{ws, -3, st, nitems * rx, ry, rz, 0, dtype, nullptr, 0, nullptr, 0}, &next)) return rc;
+    const int rc = dtype == P3D_F32
+                       ? fused_stack_impl((const float*)grids, d, w, thresh, t, (char*)ws, vertices, cap_vertices, vertex_scratch,
+                                          scratch_rows, faces, cap_faces, item_offsets, st)
+                       : fused_stack_impl((const __half*)grids, d, w, thresh, t, (char*)ws, vertices, cap_vertices,
+                                          vertex_scratch, scratch_rows, faces, cap_faces, item_offsets, st);
+    if (rc == P3D_OK) proto_commit(ws, next);
+    return rc;
 }
 
 int p3d_mc_debug_layout(int64_t rx, int64_t ry, int64_t rz, size_t* off_bits, size_t* off_records,
@@ -2304,17 +2448,11 @@ int p3d_mc_debug_face_stamps(void* buf) {   // dev build only: where k_faces lea
 }
 #endif
 
-#if P3D_RS_STATS
-int p3d_mc_debug_rs_stats(void* buf) {   // dev build only: where the DYN streaming blocks leave their life stamps
-    u64* p = (u64*)buf;
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_rs_stats), &p, sizeof(p)));
-    return P3D_OK;
-}
-#endif
+int p3d_mc_dev_hooks(void) { return P3D_DEV_HOOKS; }
 
-int p3d_mc_reload_tuning(void) {   // dev / test hook: re-read the P3D_* knobs (not for use beside running calls)
+int p3d_mc_reload_tuning(void) {   // re-read the P3D_* knobs (not for use beside running calls)
     (void)tuning();
-    g_tuning = read_tuning();
+    apply_tuning(read_tuning());
     return P3D_OK;
 }
 
@@ -2349,6 +2487,10 @@ int p3d_mc_shutdown(void) {
         }
         for (auto& pc : g_pending) pc = PendingCall();
     }
+    {
+        std::lock_guard<std::mutex> g(g_proto_mu);
+        g_proto.clear();
+    }
     if (g_ev_made) {
         for (int i = 0; i < ST_N; ++i)
             for (int j = 0; j < 2; ++j) (void)hipEventDestroy(g_ev[i][j]);
@@ -2360,8 +2502,12 @@ int p3d_mc_shutdown(void) {
 
 int p3d_mc_debug_counters(int64_t* out, int n) {
     if (!out || n < 0) return fail(P3D_EINVAL, "null pointer%s");
-    const int m = std::min(n, 5);
-    for (int i = 0; i < m; ++i) out[i] = g_counters[i].load(std::memory_order_relaxed);
+    const int m = std::min(n, 6);
+    for (int i = 0; i < std::min(m, 5); ++i) out[i] = g_counters[i].load(std::memory_order_relaxed);
+    if (m > 5) {
+        std::lock_guard<std::mutex> g(g_ring_mu);
+        out[5] = (int64_t)g_rings.size();
+    }
     return m;
 }
 

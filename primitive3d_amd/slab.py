@@ -132,8 +132,11 @@ class HipBackend:
         c = self.capi
         grid, thresh, lower, upper, full_res, ws, _ = self._state
         capf = getattr(self, "_capf", None)
-        if capf is None:  # first call: no guess yet
-            nv, nf, verts = self.finalize()
+        if capf is None:  # first call: no guess yet -- totals first (part 4 is already enqueued: launch_finalize), then faces
+            nv, nf, verts, overflow = self._read_totals()
+            self._copy_pending = not overflow
+            if overflow:
+                self._scratch = None
             faces = self._emit_faces((0, 0, rank_counts, rank))
         else:
             faces = torch.empty((capf, 3), dtype=torch.int32, device=self.device)
@@ -229,8 +232,10 @@ class SlabResult:
 
 
 class SlabExtractor:
-    def __init__(self, shape: Sequence[int], rank: int, world: int, device, dtype=torch.float32, backend=None):
+    def __init__(self, shape: Sequence[int], rank: int, world: int, device, dtype=torch.float32, backend=None,
+                 hold_planes: int = 2):
         self.shape = tuple(int(s) for s in shape)
+        self.hold_planes = max(1, int(hold_planes))   # local planes kept back for the launch that needs the halo plane
         self.rank, self.world = rank, world
         self.device = device
         self.x0, self.x1 = slab_bounds(self.shape[0], world)[rank]
@@ -271,10 +276,8 @@ class SlabExtractor:
 
     def interior_split(self) -> int:
         """First plane of the part that needs the halo plane (0 = do not split): only the last cell layer reads it; the
-        last P3D_SLAB_HOLD (default 2) local planes are held back for a short second streaming launch."""
-        import os
-        hold = max(1, int(os.environ.get("P3D_SLAB_HOLD", "2")))
-        return self.n - hold if (self.has_halo and self.n >= 24 and hasattr(self.backend, "begin_interior")) else 0
+        last `hold_planes` (default 2) local planes are held back for a short second streaming launch."""
+        return self.n - self.hold_planes if (self.has_halo and self.n >= 24 and hasattr(self.backend, "begin_interior")) else 0
 
     def phase_interior(self, thresh, lower, upper):
         """Optional: start streaming the planes that do not depend on the halo plane."""

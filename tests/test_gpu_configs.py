@@ -166,6 +166,7 @@ def test_batched_call_equals_per_item_oracle(gpu, built, shape, B, dtype):
     assert torch.equal(vo2, vo) and torch.equal(fo2, fo)
 
 
+@pytest.mark.dev_hooks
 def test_batched_call_falls_back_item_by_item(gpu, built, tuning_env):
     """P3D_TEST_ID_LIMIT makes every region report an id-space overflow: the wrapper must return the same meshes
     through its per-item path."""
@@ -177,6 +178,7 @@ def test_batched_call_falls_back_item_by_item(gpu, built, tuning_env):
         assert (int(vo[b + 1] - vo[b]), int(fo[b + 1] - fo[b])) == oracle_count(grids[b].numpy(), 0.0)
 
 
+@pytest.mark.dev_hooks
 @pytest.mark.parametrize("kind", ["stack", "single"])
 def test_chunk_prefix_handoff_under_load(gpu, built, tuning_env, kind):
     """With more than 1024 face chunks a one-block scan between the counting and the face launch (k_chunk_prefix; for a
@@ -214,6 +216,7 @@ def test_chunk_prefix_handoff_under_load(gpu, built, tuning_env, kind):
         assert torch.equal(h, h0)
 
 
+@pytest.mark.dev_hooks
 def test_batch_whose_totals_exceed_int32_goes_item_by_item(gpu, built, tuning_env):
     """Face ids are local to an item, so only an ITEM is bound by int32 -- but the one-launch path reports the batch
     totals through p3d_mc_read_counts, which refuses totals beyond int32 (P3D_ERANGE).  P3D_TEST_INDEX_LIMIT pretends

@@ -268,6 +268,7 @@ def test_adapter_on_a_row_with_a_nearly_empty_last_z_tile(gpu, built):
     assert np.array_equal(soup(v.cpu().numpy(), f.cpu().numpy()), soup(rv, rf))
 
 
+@pytest.mark.dev_hooks
 def test_region_id_space_overflow_falls_back_to_the_counting_call(gpu, built, tuning_env):
     """A region that numbers more than 2^26 vertices makes the one-pass ids ambiguous (include/p3d_mc.h,
     p3d_mc_read_counts bit 1).  P3D_TEST_ID_LIMIT pretends the id space is tiny: the flag must come back, and both the
@@ -307,10 +308,11 @@ def test_ply_of_a_device_resident_extraction(gpu, built, tmp_path):
     assert p.read_bytes() == reference_ply_bytes(vn, fn, colors.cpu().numpy())
 
 
-@pytest.mark.parametrize("env", [{"P3D_MC_MODE": "exact"}, {"P3D_MC_EXACT_ALLOC": "1"}, {}])
+@pytest.mark.parametrize("env", [{"P3D_MC_MODE": "exact"}, {"P3D_MC_MODE": "hinted"}, {}, {"P3D_MC_MODE": "fast"}])
 def test_adapter_modes_in_a_fresh_process(gpu, env):
-    """The pybind adapter's two switches are read once per process: `P3D_MC_MODE=exact` (the reference's own order: count,
-    read, allocate exactly, emit) and `P3D_MC_EXACT_ALLOC=1` (its older name).  Each must give the oracle's counts on repeated calls; with exact allocations the storage sizes are exact."""
+    """The pybind adapter's one switch is read once per process: `P3D_MC_MODE=exact` (the reference's own order: count,
+    read, allocate exactly, emit) or `hinted` (the default).  Each must give the oracle's counts on repeated calls; with
+    exact allocations the storage sizes are exact; any other value is an error, not a silent default."""
     import os
     import subprocess
     import sys
@@ -326,12 +328,15 @@ def test_adapter_modes_in_a_fresh_process(gpu, env):
             "torch.cuda.synchronize()\n"
             "print(v.shape[0], f.shape[0], v.untyped_storage().nbytes() // 12, f.untyped_storage().nbytes() // 12)\n") % str(root)
     out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=300)
+    if env.get("P3D_MC_MODE") == "fast":
+        assert out.returncode != 0 and "P3D_MC_MODE must be 'hinted' or 'exact'" in out.stderr, out.stderr[-2000:]
+        return
     assert out.returncode == 0, out.stderr[-2000:]
     g, t, _, _ = small_cases()["noise_33x17x200"]
     nv, nf = oracle_count(g, t)
     got = [int(s) for s in out.stdout.split()]
     assert got[:2] == [nv, nf]
-    if env:   # exact allocations: the storage holds exactly the rows
+    if env.get("P3D_MC_MODE") == "exact":   # exact allocations: the storage holds exactly the rows
         assert got[2:] == [nv, nf], got
     else:     # default: rows [0, V) of a buffer that may be up to 1/8 + 4096 rows longer
         assert nv <= got[2] <= nv + nv // 8 + 4096 and nf <= got[3] <= nf + nf // 8 + 4096, got

@@ -1,0 +1,217 @@
+"""The order of an extraction's calls (p3d_mc_slab.part, include/p3d_mc.h) is CHECKED by the library: every successor the
+table in the header does not have comes back as P3D_EINVAL with a message, synchronously, before anything is launched --
+the reference's boundary is stateless (marching_cubes.h:14-15), a multi-call extraction must at least be hard to misuse.
+And the per-stream cursor ring survives a call that fails between taking its block and its first launch."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import canonical_mesh, oracle_count, oracle_extract
+
+pytestmark = pytest.mark.gpu
+
+P3D_EINVAL = -1
+
+
+class Rig:
+    """One small grid with everything a part needs; call(part, ...) goes through the C ABI."""
+
+    def __init__(self, gpu, shape=(40, 24, 70), seed=5):
+        from primitive3d_amd import capi
+        from primitive3d_amd.fields import perlin_grid
+        self.capi = capi
+        self.g = perlin_grid(shape, period=12, seed=seed).to(gpu)
+        self.shape = shape
+        self.ws = torch.empty(capi.workspace_bytes(*shape), dtype=torch.uint8, device=gpu)
+        self.nv, self.nf = oracle_count(self.g.cpu().numpy(), 0.0)
+        self.scratch = torch.empty((capi.scratch_rows_for(self.nv), 3), device=gpu)
+        self.other_scratch = torch.empty_like(self.scratch)
+        self.v = torch.empty((self.nv, 3), device=gpu)
+        self.other_v = torch.empty_like(self.v)
+        self.f = torch.empty((self.nf, 3), dtype=torch.int32, device=gpu)
+        self.lower, self.upper = [0.0, 0.0, 0.0], [float(n) for n in shape]
+
+    def call(self, part, split=0, v=None, f=None, scratch="own", ws=None, grid=None):
+        slab = self.capi.Slab()
+        slab.part, slab.split_plane = part, split
+        self.capi.extract_fused_raw(self.g if grid is None else grid, 0.0, self.lower, self.upper, self.ws if ws is None else ws,
+                                    v, f, slab=slab, scratch=self.scratch if scratch == "own" else scratch)
+
+    def count(self):
+        self.capi.count(self.g, 0.0, self.ws)
+
+    def emit(self, v=None, f=None):
+        self.capi.emit(self.g, 0.0, self.lower, self.upper, self.ws, v, f)
+
+    def refuse(self, fn, *needles):
+        with pytest.raises(self.capi.P3DError) as ei:
+            fn()
+        assert ei.value.code == P3D_EINVAL, ei.value
+        msg = str(ei.value)
+        assert "illegal order of calls" in msg, msg
+        for n in needles:
+            assert n in msg, (n, msg)
+
+    def fresh(self):
+        """Forget what the workspace has seen: a starting call on another shape is not needed -- a fresh tensor is."""
+        self.ws = torch.empty_like(self.ws)
+        return self
+
+
+def _mesh_ok(rig, v, f):
+    from tests.ws_keys import vertex_keys_from_workspace
+    torch.cuda.synchronize()
+    keys = vertex_keys_from_workspace(rig.ws.cpu().numpy(), rig.shape, v.shape[0], rig.capi.debug_layout(*rig.shape))
+    ref = canonical_mesh(*oracle_extract(rig.g.cpu().numpy(), 0.0))
+    got = canonical_mesh(v.cpu().numpy(), f.cpu().numpy(), keys)
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+
+
+def test_every_illegal_successor_is_refused(gpu):
+    r = Rig(gpu)
+    split = 16
+    # on a workspace that has seen nothing: every continuation
+    for part, kw in [(2, dict(split=split)), (3, dict(split=split)), (4, {}), (5, {}), (6, dict(v=r.v, f=r.f))]:
+        r.fresh()
+        r.refuse(lambda: r.call(part, **kw), "none is in progress" if part != 6 else "")
+    r.fresh()
+    r.refuse(lambda: r.emit(r.v, r.f), "p3d_mc_emit needs")
+    # after part 1: only 2 or 3 at the same split
+    for part, kw, needle in [(4, {}, "part 4 needs part 3"), (5, {}, "part 5 needs part 4"), (6, dict(v=r.v, f=r.f), "part 6 needs"),
+                             (2, dict(split=split + 1), "split_plane"), (3, dict(split=split + 2), "split_plane")]:
+        r.fresh().call(1, split=split)
+        r.refuse(lambda: r.call(part, **kw), needle, "part 1")
+    r.fresh().call(1, split=split)
+    r.refuse(lambda: r.emit(r.v, r.f), "finished counts")
+    # after part 3: only 4
+    for part, kw, needle in [(2, dict(split=split), "part 2 needs part 1"), (5, {}, "part 5 needs part 4"),
+                             (6, dict(v=r.v, f=r.f), "part 6 needs"), (3, dict(split=split), "needs part 1")]:
+        r.fresh().call(3)
+        r.refuse(lambda: r.call(part, **kw), needle, "part 3")
+    r.fresh().call(3)
+    r.refuse(lambda: r.emit(r.v, r.f), "finished counts")
+    # after part 4 WITHOUT a vertex buffer: part 5 may not write vertices (6 does); after part 4 WITH one: the same one
+    r.fresh().call(3)
+    r.call(4)
+    r.refuse(lambda: r.call(5, v=r.v, f=r.f), "part 6 writes the vertices")
+    r.refuse(lambda: r.call(2, split=split), "part 2 needs part 1")
+    r.refuse(lambda: r.call(4), "part 4 needs part 3")
+    r.fresh().call(3)
+    r.call(4, v=r.v)
+    r.refuse(lambda: r.call(5, v=r.other_v, f=r.f), "vertex buffer part 4 began to fill")
+    r.refuse(lambda: r.call(5, v=None, f=r.f), "vertex buffer part 4 began to fill")
+    # after a finished extraction: 6 (same scratch) and emit are fine, 2 / 4 / 5 are not
+    r.fresh().call(0, v=r.v, f=r.f)
+    for part, kw, needle in [(2, dict(split=split), "part 2 needs part 1"), (4, {}, "part 4 needs part 3"), (5, {}, "part 5 needs part 4")]:
+        r.refuse(lambda: r.call(part, **kw), needle, "finished extraction")
+    # p3d_mc_count starts anew: parts cannot continue it
+    r.fresh().count()
+    for part, kw in [(2, dict(split=split)), (4, {}), (5, {}), (6, dict(v=r.v, f=r.f))]:
+        r.refuse(lambda: r.call(part, **kw), "p3d_mc_count")
+    # the batched entry: nothing continues it
+    grids = r.g[None].contiguous()
+    wsb = torch.empty(r.capi.workspace_bytes_batched(1, *r.shape), dtype=torch.uint8, device=gpu)
+    off = torch.zeros(4, dtype=torch.int64, device=gpu)
+    r.capi.extract_fused_batched_raw(grids, 0.0, r.lower, r.upper, wsb, r.v, r.scratch, r.f, off)
+    r.refuse(lambda: r.call(6, v=r.v, f=r.f, ws=wsb), "p3d_mc_extract_fused_batched")
+
+
+def test_same_stream_shape_and_scratch_are_enforced(gpu):
+    r = Rig(gpu)
+    r.call(3)
+    r.refuse(lambda: r.call(4, scratch=r.other_scratch), "scratch")
+    s2 = torch.cuda.Stream(device=gpu)
+    with torch.cuda.stream(s2):
+        r.refuse(lambda: r.call(4), "same stream")
+    smaller = r.g[:-1].contiguous()
+    r.refuse(lambda: r.call(4, grid=smaller), "same grid shape")
+    r.call(4)   # the refused calls changed nothing: the legal successor still is
+    r.refuse(lambda: r.call(6, v=r.v, f=r.f, scratch=r.other_scratch), "scratch")
+    r.call(6, v=r.v, f=r.f)
+    _mesh_ok(r, r.v, r.f)
+    s2.synchronize()
+    r.capi.release_stream(s2.cuda_stream)
+
+
+def test_the_legal_walks_give_the_oracles_mesh(gpu):
+    r = Rig(gpu)
+    split = 16
+    # 1 -> 3 -> 4 -> 5
+    r.call(1, split=split, v=r.v)
+    r.call(3, split=split, v=r.v)
+    r.call(4, v=r.v)
+    assert r.capi.read_counts(r.ws) == (r.nv, r.nf)
+    r.call(5, v=r.v, f=r.f)
+    _mesh_ok(r, r.v, r.f)
+    # 1 -> 2 (finished) -> 6 into other buffers -> 6 again
+    r.fresh().call(1, split=split, v=r.v)
+    r.call(2, split=split, v=r.v, f=r.f)
+    assert r.capi.read_counts(r.ws) == (r.nv, r.nf)
+    r.other_v.fill_(float("nan"))
+    r.call(6, v=r.other_v, f=r.f)
+    _mesh_ok(r, r.other_v, r.f)
+    r.call(6, v=r.v, f=r.f)
+    _mesh_ok(r, r.v, r.f)
+    # 3 -> 4 -> 6, then the gather emitter on the same workspace; a starting part is legal at any time
+    r.fresh().call(3)
+    r.call(4)
+    r.call(6, v=r.v, f=r.f)
+    _mesh_ok(r, r.v, r.f)
+    r.emit(r.other_v, r.f)
+    r.call(3)
+    r.call(0, v=r.v, f=r.f)
+    r.count()
+    r.emit(r.v, r.f)
+    torch.cuda.synchronize()
+
+
+def test_a_recycled_workspace_address_inherits_nothing(gpu):
+    """The table is keyed by the workspace POINTER: the caching allocator hands the same address out again.  A starting part
+    resets the entry, so the new owner's legal sequence is legal whatever the old owner did last."""
+    r = Rig(gpu)
+    r.call(1, split=16, v=r.v)          # ... and the extraction is abandoned
+    addr = r.ws.data_ptr()
+    n = r.ws.numel()
+    r.ws = None
+    ws2 = torch.empty(n, dtype=torch.uint8, device=gpu)
+    if ws2.data_ptr() != addr:
+        pytest.skip("the allocator did not hand the address out again")
+    r.ws = ws2
+    r.call(3)
+    r.call(4)
+    r.call(6, v=r.v, f=r.f)
+    _mesh_ok(r, r.v, r.f)
+
+
+@pytest.mark.dev_hooks
+def test_the_cursor_ring_survives_a_call_that_fails_after_its_lease(gpu, built, tuning_env):
+    """cursor_block_for hands a whole-grid call the stream's next pre-cleared block; the call's streaming kernel clears the
+    block after it.  The ring moves on only when that kernel is enqueued (RingLease::commit): a call that fails in between
+    (hook P3D_TEST_FAIL_AFTER_LEASE) must leave the following calls on clean blocks -- before round 5 `cur` advanced at the
+    lease and the next call got a block nobody had cleared."""
+    from primitive3d_amd import capi
+    from primitive3d_amd.fields import perlin_grid
+    g = perlin_grid((48, 40, 130), period=14, seed=9).to(gpu)
+    ref = oracle_count(g.cpu().numpy(), 0.0)
+    for _ in range(5):   # every block of the ring has been used (dirty unless cleared by the call before)
+        v, f = built.marching_cubes(g, 0.0)
+        assert (v.shape[0], f.shape[0]) == ref
+    for fails in (1, 3):
+        tuning_env("P3D_TEST_FAIL_AFTER_LEASE", str(fails))
+        for _ in range(fails):
+            with pytest.raises(RuntimeError, match="injected failure"):
+                built.marching_cubes(g, 0.0)
+        for _ in range(6):   # more than a whole turn of the ring
+            v, f, k = None, None, None
+            v, f = built.marching_cubes(g, 0.0)
+            assert (v.shape[0], f.shape[0]) == ref
+            assert int(f.max()) == ref[0] - 1 and int(f.min()) == 0
+        hv, hf = capi.extract_fused(g, 0.0)
+        assert (hv.shape[0], hf.shape[0]) == ref
+    tuning_env("P3D_TEST_FAIL_AFTER_LEASE", None)
+    # whole mesh after the storm
+    from tests.test_gpu_parity import _assert_same_mesh, _hip_extract_fused
+    _assert_same_mesh(_hip_extract_fused(gpu, g.cpu().numpy(), 0.0, None, None), oracle_extract(g.cpu().numpy(), 0.0))

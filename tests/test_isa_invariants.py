@@ -5,9 +5,7 @@ without a GPU, so this runs in the CPU suite):
     a vector atomic in its place would queue its result behind the wave's vector stores and plane loads again;
   * its destination register is written ASYNCHRONOUSLY (the compiler does not know): nothing may read, copy or spill it
     between the atomic and the hand-written `s_waitcnt lgkmcnt(0)` that hands it over;
-  * the DYN variants claim their next plane with a VECTOR atomic (`global_atomic_add_x2`, the compiler tracks its result):
-    a second scalar atomic would put a memory round trip into the first LDS wait of every plane (measured: 7.0 vs 4.8 us
-    per plane);
+  * no other atomic lives in that kernel;
   * no k_fused / k_faces / k_face_count_walk variant uses scratch memory.
 """
 import re
@@ -61,15 +59,11 @@ def _sregs(text):
 
 def test_cursor_atomic_is_scalar(device_asm):
     kernels = _kernels(device_asm, "k_fused")
-    assert len(kernels) >= 12   # 4 tile geometries x 2 sample types, + the DYN variants of the 8 x 3 and 4 x 6 tiles
+    assert len(kernels) == 8   # 4 tile geometries x 2 sample types (the round-4 DYN variants left in round 5)
     for name, body in kernels.items():
-        dyn = "Lb1E" in name
         assert body.count("s_atomic_add ") == 2, name        # one per half of the unrolled plane loop
         assert "s_atomic_add_x2" not in body and "buffer_atomic" not in body, name
-        # DYN: the leader's plane claim (one per half of the plane loop), + the hand-out table's exchange / compare-and-swap
-        assert body.count("global_atomic_add_x2 ") == (2 if dyn else 0), name
-        if not dyn:
-            assert "global_atomic" not in body, name
+        assert "global_atomic" not in body, name
         # the results are awaited by the hand-written scalar-counter wait, right in front of the slot computation
         assert len(_WAIT.findall(body)) >= 2, name
 
@@ -77,8 +71,8 @@ def test_cursor_atomic_is_scalar(device_asm):
 def test_async_atomic_results_are_left_alone(device_asm):
     """`got` is an SGPR written by a scalar atomic that is still in flight when its asm statement ends.  Between
     the atomic and the next hand-written lgkmcnt(0) wait no instruction may mention it -- a copy or a spill there would
-    read the stale value (a first version of the DYN plane claim did exactly that with a second scalar atomic: the
-    compiler moved the operand to another register pair in front of the wait)."""
+    read the stale value (a round-4 experiment did exactly that with a second scalar atomic: the compiler moved the
+    operand to another register pair in front of the wait)."""
     for name, body in _kernels(device_asm, "k_fused").items():
         lines = body.split("\n")
         checked = 0
@@ -108,4 +102,4 @@ def test_no_scratch_in_the_benchmarked_variants(device_asm):
         size = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", desc).group(1))
         assert size == 0, (name, size)
         seen += 1
-    assert seen >= 16
+    assert seen >= 12

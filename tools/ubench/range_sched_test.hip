@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "../../primitive3d_amd/csrc/range_sched.h"
+#include "range_sched.h"
 typedef unsigned int u32;
 typedef unsigned long long u64;
 
