@@ -141,9 +141,16 @@ def marching_cubes_batched(density_grids, thresh: float, scale=None):
     ws = torch.empty(capi.workspace_bytes_batched(B, *shape), dtype=torch.uint8, device=dev)
     offs = torch.empty(2 * (B + 1), dtype=torch.int64, device=dev)
     key = (dev.index, B) + shape
-    if _BATCH_HINTS.get(key) == "per_item":   # (an earlier call found the batch's totals beyond int32)
+    hint = _BATCH_HINTS.get(key)
+    if hint is not None and hint[0] == "per_item":   # (an earlier call found the batch's totals beyond int32)
+        # the marker expires: after _PER_ITEM_CALLS calls the one-launch path is tried again -- later batches of the shape
+        # may be sparser (it used to stay for the life of the process)
+        if hint[1] > 1:
+            _BATCH_HINTS[key] = ("per_item", hint[1] - 1)
+        else:
+            _BATCH_HINTS.pop(key, None)
         return _batched_item_by_item(density_grids, thresh, lower, upper)
-    capv, capf, slack = _BATCH_HINTS.get(key, (max(4096, nvox // 16), 2 * max(4096, nvox // 16), 5))
+    capv, capf, slack = hint if hint is not None else (max(4096, nvox // 16), 2 * max(4096, nvox // 16), 5)
     for attempt in range(3):
         per_region = (capv + 32 * B - 1) // (32 * B)
         rows = 32 * B * max(per_region * slack // 4 + 256, min(capv, 2048))
@@ -159,7 +166,7 @@ def marching_cubes_batched(density_grids, thresh: float, scale=None):
             # the TOTALS of the batch exceed int32 although face ids are local to an item: item by item, every item
             # is checked against the limit on its own -- and later calls on this shape go there directly instead of
             # allocating and streaming the whole batch first
-            _remember_batch(key, "per_item")
+            _remember_batch(key, ("per_item", _PER_ITEM_CALLS))
             break
         fitted = nv <= capv and nf <= capf and not flags
         _remember_batch(key, (nv + nv // 8 + 4096, nf + nf // 8 + 4096, min(32, 2 * slack) if flags & 1 else slack))
@@ -171,7 +178,8 @@ def marching_cubes_batched(density_grids, thresh: float, scale=None):
     return _batched_item_by_item(density_grids, thresh, lower, upper)
 
 
-_BATCH_HINTS = {}   # (device, B, rx, ry, rz) -> (vertex capacity, face capacity, scratch slack in quarters) | "per_item"
+_BATCH_HINTS = {}   # (device, B, rx, ry, rz) -> (vertex capacity, face capacity, scratch slack in quarters) | ("per_item", calls left)
+_PER_ITEM_CALLS = 16
 
 
 def _remember_batch(key, hint):

@@ -231,7 +231,8 @@ def test_batch_whose_totals_exceed_int32_goes_item_by_item(gpu, built, tuning_en
     key = (gpu.index, 3, 9, 10, 20)
     try:
         passes = []
-        for call in range(2):
+        ncalls = mcmod._PER_ITEM_CALLS + 2
+        for call in range(ncalls):
             before = capi.debug_counters()["streaming_passes"]
             v, f, vo, fo = built.marching_cubes_batched(grids.to(gpu), 0.0)
             passes.append(capi.debug_counters()["streaming_passes"] - before)
@@ -239,10 +240,15 @@ def test_batch_whose_totals_exceed_int32_goes_item_by_item(gpu, built, tuning_en
                 assert (int(vo[b + 1] - vo[b]), int(fo[b + 1] - fo[b])) == counts[b]
                 fb = f[fo[b]:fo[b + 1]]
                 assert int(fb.min()) >= 0 and int(fb.max()) < counts[b][0]
-        # the first call streams the whole batch once before it learns of the limit; the second goes item by item at once
-        # (it used to allocate and stream the batch again on every call)
-        assert mcmod._BATCH_HINTS.get(key) == "per_item"
+            if call == 0:
+                assert mcmod._BATCH_HINTS.get(key) == ("per_item", mcmod._PER_ITEM_CALLS)
+        # the first call streams the whole batch once before it learns of the limit; the next ones go item by item at once
+        # (it used to allocate and stream the batch again on every call) -- until the marker has expired: the
+        # one-launch path is then tried again (it used to stay for the life of the process), here only to learn
+        # of the limit once more
         assert passes[0] > passes[1] >= 3, passes
+        assert passes[1:mcmod._PER_ITEM_CALLS + 1] == [passes[1]] * mcmod._PER_ITEM_CALLS, passes
+        assert passes[mcmod._PER_ITEM_CALLS + 1] == passes[0], passes
     finally:
         mcmod._BATCH_HINTS.pop(key, None)
 
