@@ -174,7 +174,7 @@ def other_configs(p3d, capi, perlin_grid, dev):
     return out
 
 
-def rank_slab_workload(capi, perlin_grid, dev, world=8, rank=3, shape=(1024, 1024, 1024), steps=12, warmup=4):
+def rank_slab_workload(capi, perlin_grid, dev, world=8, rank=3, shape=(1024, 1024, 1024), steps=12, warmup=4, hold=2):
     """What ONE rank of the 8-GPU run of BASELINE.json configs[3] does per step, on this GPU: rank 3's slab of the 1024^3
     volume -- 128 planes + the halo plane -- through SlabExtractor.extract()'s real sequence (interior planes streamed
     while the halo plane would travel: part 1; the last planes + header: part 3; export of the first plane's records for the
@@ -185,7 +185,7 @@ def rank_slab_workload(capi, perlin_grid, dev, world=8, rank=3, shape=(1024, 102
     import torch
     import torch.distributed as dist
     from primitive3d_amd.slab import SlabExtractor
-    ex = SlabExtractor(shape, rank, world, dev)
+    ex = SlabExtractor(shape, rank, world, dev, hold_planes=hold)
     ex.fill_local(lambda x0, x1: perlin_grid(shape, period=64, seed=0, device=dev, x0=x0, x1=x1))
     halo_src = perlin_grid(shape, period=64, seed=0, device=dev, x0=ex.x1, x1=ex.x1 + 1)[0].contiguous()
     rec_src = {}
@@ -205,8 +205,9 @@ def rank_slab_workload(capi, perlin_grid, dev, world=8, rank=3, shape=(1024, 102
         return []
 
     def _all_gather(out_t, inp):
-        out_t.zero_()   # (the other ranks' rows: their counts would arrive here)
-        out_t.view(world, -1)[rank].copy_(inp.view(-1))
+        # (ONE device copy, like the collective it stands in for: every row receives this rank's header words -- the other
+        #  ranks' counts would arrive here; similar slabs have similar counts, so the id bases are realistic)
+        out_t.view(world, -1).copy_(inp.view(1, -1).expand(world, -1))
 
     saved = {k: getattr(dist, k, None) for k in ("get_backend", "P2POp", "batch_isend_irecv", "all_gather_into_tensor", "isend", "irecv")}
     try:
@@ -264,6 +265,21 @@ def child_exact_mode(steps, warmup):
     print(json.dumps({"ms_per_step": round(ms, 4), "steps": steps,
                       "streaming_passes_per_call": (capi.debug_counters()["streaming_passes"] - p0) / steps,
                       "vertices": int(out[0].shape[0]), "faces": int(out[1].shape[0])}))
+
+
+def child_fresh(steps, warmup):
+    """`--child fresh` (run under rocprofv3 --kernel-trace --stats by tools/profile_round.sh): modes.fresh_grid's call stream
+    alone -- four distinct 512^3 grids taken in turn -- so that the profiler's average for k_fused can be set beside the
+    headline's (the headline re-extracts one resident grid)."""
+    import torch
+    import primitive3d_amd as p3d
+    from primitive3d_amd.fields import perlin_grid
+    dev = torch.device("cuda", 0)
+    grids = [perlin_grid(SHAPES[1], period=64, seed=sd, device=dev) for sd in range(4)]
+    up = [float(s) for s in SHAPES[1]]
+    for i in range(warmup + steps):
+        p3d.libPrim3D.marching_cubes(grids[i % 4], 0.0, [0.0] * 3, up)
+    torch.cuda.synchronize()
 
 
 def child_stream(steps, warmup):
@@ -471,6 +487,8 @@ def main():
         return child_exact_mode(args.steps, args.warmup)
     if args.child == "stream":
         return child_stream(args.steps, args.warmup)
+    if args.child == "fresh":
+        return child_fresh(args.steps, args.warmup)
 
     import torch
     import torch.distributed as dist

@@ -104,7 +104,7 @@ typedef struct p3d_mc_slab {
                                     (vertex_id_base = sum of the counts of ranks < rank, halo base = that + this
                                     rank's count) and ignores the two fields above: the host never waits for the
                                     other ranks' counts, the all-gather result stays on the device. */
-    int32_t rank;                /* index of this rank in rank_counts */
+    int32_t rank;                /* index of this rank in rank_counts: 0..63 (one lane of a wave loads one rank's count) */
     int32_t rank_counts_stride;  /* int64 elements between two ranks' counts (0 = 1): the multi-GPU wrapper all-gathers
                                     the first three header words of every rank's workspace (V, -, flags), so that every
                                     rank also learns every rank's overflow flags; the counts are then 3 apart */

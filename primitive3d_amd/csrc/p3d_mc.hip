@@ -1055,14 +1055,12 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     //   lane 32      the tile's triangle count          lanes 33..36  the first face of the tile's four waves in its chunk
     //   lane 37      the chunk's exclusive prefix (when the counting launch left one)
     const u32 mychunk32 = item * (u32)a.cpi + (xl >> a.xw_shift) * (u32)a.tpp + (u32)tile;
-    // (multi-GPU slabs: the id bases come from the all-gathered vertex counts -- scalar loads, in front of the vector loads)
+    // (multi-GPU slabs: the id bases come from the all-gathered vertex counts -- lane r loads rank r's count, ONE vector
+    //  load that travels with the prologue's batch below; a scalar loop over the ranks was rank + 1 serial round trips in
+    //  front of every tile's loads: the higher a rank, the slower its face launch)
     u32 b0 = (u32)a.vid_base, bhalo = (u32)a.halo_vid_base;
-    if (a.rank_counts) {
-        int64_t acc = 0;
-        for (int r = 0; r < a.rank; ++r) acc += a.rank_counts[(size_t)r * a.rank_stride];
-        b0 = (u32)acc;
-        bhalo = (u32)(acc + a.rank_counts[(size_t)a.rank * a.rank_stride]);
-    }
+    const u32* rcp = (const u32*)a.tile_tris;   // (idle lanes: any valid address)
+    if (a.rank_counts && (int)(threadIdx.x & 63) <= a.rank) rcp = (const u32*)(a.rank_counts + (size_t)(threadIdx.x & 63) * a.rank_stride);
     // (every lane has a valid address and the loads are unconditional: one basic block, so that the compiler lets all the
     //  prologue's loads leave before it waits for the first)
     const u32* mp = a.tile_tris + b;
@@ -1120,6 +1118,7 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     auto ld32 = [](const void* p) -> u32 { return __hip_atomic_load((const u32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     auto ld64 = [](const void* p) -> u64 { return __hip_atomic_load((const u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     const u32 misc = ld32(mp);
+    const u32 rcv = ld32(rcp);   // (the low dword of a rank's count: the totals stay below 2^31, SlabExtractor checks)
     u32 part[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) part[k] = ld32(cp4[k]);
@@ -1154,6 +1153,11 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
         st_y1[q] = st_up[q] ? lw[4 * q + 3] : 0ull;
         st_r0[q] = st_in[q] ? lr[2 * q + 0] : make_uint2(0u, 0u);
         st_r1[q] = st_in[q] ? lr[2 * q + 1] : make_uint2(0u, 0u);
+    }
+    if (a.rank_counts) {   // (wave-uniform; every wave computes the two bases for itself)
+        const u32 inc = wave_prefix_sum(lane <= a.rank ? rcv : 0u);
+        bhalo = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+        b0 = bhalo - (u32)__builtin_amdgcn_readlane((int)rcv, a.rank & 63);
     }
     u32 cs = 0;
     if (!a.chunk_pre) {
@@ -2334,6 +2338,8 @@ int p3d_mc_emit(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz,
                 int64_t cap_vertices, int32_t* faces, int64_t cap_faces, int64_t* vertex_keys, void* stream) {
     if (!grid || !ws || !lower || !upper) return fail(P3D_EINVAL, "null pointer%s");
     if ((cap_vertices > 0 && !vertices) || (cap_faces > 0 && !faces)) return fail(P3D_EINVAL, "null output%s");
+    if (slab && slab->rank_counts && (slab->rank < 0 || slab->rank >= 64))
+        return fail(P3D_EINVAL, "rank_counts serves ranks 0..63 (one lane of a wave per rank)%s");
     if (int rc = check_dims(rx, ry, rz)) return rc;
     const Dims d = make_dims(rx, ry, rz);
     const Ws w = make_ws(d);
@@ -2361,6 +2367,8 @@ int p3d_mc_extract_fused(const void* grid, int dtype, int64_t rx, int64_t ry, in
         return fail(P3D_EINVAL, "vertex output needs a scratch buffer of at least 32 rows%s");
     if (int rc = check_dims(rx, ry, rz)) return rc;
     if (slab && (slab->part < 0 || slab->part > 6)) return fail(P3D_EINVAL, "bad slab part%s");
+    if (slab && slab->rank_counts && (slab->rank < 0 || slab->rank >= 64))
+        return fail(P3D_EINVAL, "rank_counts serves ranks 0..63 (one lane of a wave per rank)%s");
     if (slab && (slab->part == 1 || slab->part == 2) && (slab->split_plane < 1 || slab->split_plane >= rx))
         return fail(P3D_EINVAL, "bad split_plane%s");
     if (slab && slab->part == 3 && (slab->split_plane < 0 || slab->split_plane >= rx))

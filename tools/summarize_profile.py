@@ -26,7 +26,8 @@ def short(name):
     return None
 
 
-for sub, label in (("stats", "headline c3"), ("stats_c5", "c5 batch"), ("stats_c2", "c2 bunny")):
+for sub, label in (("stats", "headline c3"), ("stats_fresh", "c3, four distinct grids in turn (modes.fresh_grid)"), ("stats_c5", "c5 batch"),
+                   ("stats_c2", "c2 bunny")):
     rows = []
     for f in glob.glob(d + f"/{sub}/**/*kernel_stats.csv", recursive=True):
         for r in csv.DictReader(open(f)):
