@@ -2271,10 +2271,10 @@ void proto_commit(const void* ws, const Extraction& e_in) {
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     std::lock_guard<std::mutex> g(g_proto_mu);
     if (g_proto.size() >= kMaxExtractions && g_proto.find({dev, ws}) == g_proto.end()) {
-        auto oldest = g_proto.begin();
-        for (auto it = g_proto.begin(); it != g_proto.end(); ++it)
-            if (it->second.last_use < oldest->second.last_use) oldest = it;
-        g_proto.erase(oldest);
+        // full: the older half goes in one sweep (amortised O(1) per call; entries are stamped with a running clock)
+        const uint64_t keep_from = g_proto_clock > kMaxExtractions / 2 ? g_proto_clock - kMaxExtractions / 2 : 0;
+        for (auto it = g_proto.begin(); it != g_proto.end();)
+            it = it->second.last_use < keep_from ? g_proto.erase(it) : std::next(it);
     }
     Extraction e = e_in;
     e.last_use = ++g_proto_clock;

@@ -215,3 +215,18 @@ def test_the_cursor_ring_survives_a_call_that_fails_after_its_lease(gpu, built, 
     # whole mesh after the storm
     from tests.test_gpu_parity import _assert_same_mesh, _hip_extract_fused
     _assert_same_mesh(_hip_extract_fused(gpu, g.cpu().numpy(), 0.0, None, None), oracle_extract(g.cpu().numpy(), 0.0))
+
+
+def test_the_table_holds_the_most_recent_workspaces(gpu):
+    """The host-side table keeps the 1024 most recently used workspaces (the older half goes in one sweep when it is full):
+    an extraction left unfinished on a workspace that fell out is 'not in progress' any more -- refused, never garbage."""
+    from primitive3d_amd import capi
+    r = Rig(gpu, shape=(6, 8, 70))
+    n = capi.workspace_bytes(*r.shape)
+    pool = [torch.empty(n, dtype=torch.uint8, device=gpu) for _ in range(1600)]
+    for ws in pool:
+        r.call(3, ws=ws)
+    r.refuse(lambda: r.call(4, ws=pool[0]), "none is in progress")
+    r.call(4, ws=pool[-1])          # the most recent ones are all there
+    r.call(4, ws=pool[-500])
+    torch.cuda.synchronize()
