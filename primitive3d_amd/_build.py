@@ -74,6 +74,8 @@ def pybind_path() -> Path:
 
 def build_capi(force: bool = False, verbose: bool = False, dev: bool = False) -> Path:
     import time
+    if not dev and os.environ.get("P3D_CAPI_LIB"):
+        return capi_path()   # someone else's build, bound for an A/B run: never rebuilt over (it has no stamp of ours)
     out = capi_dev_path() if dev else capi_path()
     flags = CAPI_EXTRA_FLAGS + (["-DP3D_DEV_HOOKS=1"] if dev else [])
     deps = [CSRC / "p3d_mc.hip", *sorted(CSRC.glob("*.inc")), *sorted(CSRC.glob("*.h")), ROOT / "include" / "p3d_mc.h"]
