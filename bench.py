@@ -200,8 +200,9 @@ def rank_slab_workload(capi, perlin_grid, dev, world=8, rank=3, shape=(1024, 102
                 if o.tensor.shape == halo_src.shape and o.tensor.dtype == halo_src.dtype:
                     o.tensor.copy_(halo_src)
                 else:
-                    src = rec_src.setdefault(o.tensor.numel(), torch.zeros(o.tensor.numel(), dtype=o.tensor.dtype, device=dev))
-                    o.tensor.copy_(src)
+                    if o.tensor.numel() not in rec_src:   # (made once: a fill kernel per step would be the stub's cost, not the path's)
+                        rec_src[o.tensor.numel()] = torch.zeros(o.tensor.numel(), dtype=o.tensor.dtype, device=dev)
+                    o.tensor.copy_(rec_src[o.tensor.numel()])
         return []
 
     def _all_gather(out_t, inp):

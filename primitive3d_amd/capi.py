@@ -211,6 +211,82 @@ def extract_fused_raw(grid, thresh, lower, upper, ws, vertices, faces, slab=None
                "p3d_mc_extract_fused")
 
 
+class FusedCaller:
+    """p3d_mc_extract_fused / p3d_mc_emit / p3d_mc_read_counts / p3d_mc_export_plane_records on ONE grid and workspace with
+    everything that does not change between the parts of an extraction marshalled once: the grid, the box, the workspace, the
+    stream (the current one when this object is made) -- the multi-GPU path makes four to six calls per extraction, and
+    building the ctypes arguments (two `torch.cuda.current_stream` look-ups, three arrays, a device guard) cost more host
+    time per call than the library spends in it.  The caller keeps the tensors alive and stays on the device and stream it
+    was on (SlabExtractor does)."""
+
+    def __init__(self, grid, thresh, lower, upper, ws, full_res=None):
+        import torch
+        assert grid.is_cuda and grid.is_contiguous() and grid.dim() == 3
+        self.L = lib()
+        self.dev = grid.device
+        self.shape = tuple(int(n) for n in grid.shape)
+        self.grid_p, self.ws_p, self.dtype = c_void_p(grid.data_ptr()), c_void_p(ws.data_ptr()), _dtype_code(grid)
+        self.thresh = c_float(thresh)
+        self.lo = (c_float * 3)(*[float(v) for v in lower])
+        self.up = (c_float * 3)(*[float(v) for v in upper])
+        self.fr = (c_int64 * 3)(*[int(v) for v in full_res]) if full_res is not None else None
+        self.stream = c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        self._keep = (grid, ws)
+
+    def _guard(self):
+        import torch
+        return torch.cuda.device(self.dev) if torch.cuda.current_device() != self.dev.index else _NoGuard
+
+    def fused(self, slab, vertices, scratch, faces):
+        capv = vertices.shape[0] if vertices is not None else 0
+        capf = faces.shape[0] if faces is not None else 0
+        rx, ry, rz = self.shape
+        with self._guard():
+            _check(self.L.p3d_mc_extract_fused(self.grid_p, self.dtype, rx, ry, rz, self.thresh, byref(self.lo), byref(self.up),
+                                               byref(self.fr) if self.fr is not None else None,
+                                               byref(slab) if slab is not None else None, self.ws_p,
+                                               c_void_p(vertices.data_ptr()) if capv else None, capv,
+                                               c_void_p(scratch.data_ptr()) if scratch is not None else None,
+                                               scratch.shape[0] if scratch is not None else 0,
+                                               c_void_p(faces.data_ptr()) if capf else None, capf, self.stream),
+                   "p3d_mc_extract_fused")
+
+    def emit(self, slab, vertices, faces):
+        capv = vertices.shape[0] if vertices is not None else 0
+        capf = faces.shape[0] if faces is not None else 0
+        rx, ry, rz = self.shape
+        with self._guard():
+            _check(self.L.p3d_mc_emit(self.grid_p, self.dtype, rx, ry, rz, self.thresh, byref(self.lo), byref(self.up),
+                                      byref(self.fr) if self.fr is not None else None,
+                                      byref(slab) if slab is not None else None, self.ws_p,
+                                      c_void_p(vertices.data_ptr()) if capv else None, capv,
+                                      c_void_p(faces.data_ptr()) if capf else None, capf, None, self.stream), "p3d_mc_emit")
+
+    def read_counts(self):
+        v, f, o = c_int64(0), c_int64(0), c_int32(0)
+        with self._guard():
+            _check(self.L.p3d_mc_read_counts(self.ws_p, byref(v), byref(f), byref(o), self.stream), "p3d_mc_read_counts")
+        return v.value, f.value, int(o.value)
+
+    def export_plane_records(self, plane, out):
+        rx, ry, rz = self.shape
+        with self._guard():
+            _check(self.L.p3d_mc_export_plane_records(self.ws_p, rx, ry, rz, plane, c_void_p(out.data_ptr()), self.stream),
+                   "p3d_mc_export_plane_records")
+        return out
+
+
+class _NoGuardType:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NoGuard = _NoGuardType()
+
+
 def workspace_bytes_batched(nitems, rx, ry, rz) -> int:
     n = c_size_t(0)
     _check(lib().p3d_mc_workspace_bytes_batched(nitems, rx, ry, rz, byref(n)), "p3d_mc_workspace_bytes_batched")

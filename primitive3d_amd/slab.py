@@ -47,12 +47,18 @@ class HipBackend:
         self._cap = None  # output-size hint from the previous call
         self._ws = None
 
-    def _prepare(self, grid, x_origin, halo):
+    def _prepare(self, grid, x_origin, halo, thresh=None, lower=None, upper=None, full_res=None):
         c = self.capi
         rx, ry, rz = grid.shape
-        nbytes = c.workspace_bytes(rx, ry, rz)
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        if getattr(self, "_ws_shape", None) != (rx, ry, rz):
+            nbytes = c.workspace_bytes(rx, ry, rz)
+            if self._ws is None or self._ws.numel() < nbytes:
+                self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws_shape = (rx, ry, rz)
+            ptr, self._plane_bytes = c.plane_records(self._ws, rx, ry, rz, 0)
+            self._rec0_off = ptr - self._ws.data_ptr()
+        # everything the parts of this extraction have in common, marshalled once (capi.FusedCaller)
+        self._call = c.FusedCaller(grid, thresh, lower, upper, self._ws, full_res) if thresh is not None else None
         capv = self._cap if self._cap is not None else max(4096, rx * ry * rz // 16)
         self._verts = torch.empty((capv, 3), dtype=torch.float32, device=self.device)
         self._scratch = torch.empty((c.scratch_rows_for(capv), 3), dtype=torch.float32, device=self.device)
@@ -63,10 +69,9 @@ class HipBackend:
 
     def begin_interior(self, grid, thresh, lower, upper, full_res, x_origin, halo, split):
         """Stream planes [0, split): they do not touch the halo plane, so this can run while it is in flight."""
-        self._prepare(grid, x_origin, halo)
+        self._prepare(grid, x_origin, halo, thresh, lower, upper, full_res)
         self._split = split
-        self.capi.extract_fused_raw(grid, thresh, lower, upper, self._ws, self._verts, None, slab=self._mk(1, split),
-                                    full_res=full_res, scratch=self._scratch)
+        self._call.fused(self._mk(1, split), self._verts, self._scratch, None)
 
     def stream_rest(self, grid, thresh, lower, upper, full_res, x_origin, halo):
         """Stream the planes not yet streamed and leave V and the id prefixes in the workspace header (no finalize):
@@ -74,9 +79,8 @@ class HipBackend:
         c = self.capi
         split = getattr(self, "_split", 0)
         if not split:
-            self._prepare(grid, x_origin, halo)
-        c.extract_fused_raw(grid, thresh, lower, upper, self._ws, self._verts, None, slab=self._mk(3, split),
-                            full_res=full_res, scratch=self._scratch)
+            self._prepare(grid, x_origin, halo, thresh, lower, upper, full_res)
+        self._call.fused(self._mk(3, split), self._verts, self._scratch, None)
         self._state = (grid, thresh, lower, upper, full_res, self._ws, None)
 
     def header_vertex_count(self):
@@ -90,10 +94,7 @@ class HipBackend:
 
     def launch_finalize(self):
         """Part 4: face count + the first slices of the vertex compaction; V and F go to the host mailbox."""
-        grid, thresh, lower, upper, full_res, ws, _ = self._state
-        self.capi.extract_fused_raw(grid, thresh, lower, upper, ws, self._verts, None,
-                                    slab=self._mk(4, getattr(self, "_split", 0)), full_res=full_res,
-                                    scratch=self._scratch)
+        self._call.fused(self._mk(4, getattr(self, "_split", 0)), self._verts, self._scratch, None)
         self._split = 0
         self._slab = self._mk()
 
@@ -102,7 +103,7 @@ class HipBackend:
         c = self.capi
         grid, thresh, lower, upper, full_res, ws, _ = self._state
         verts = self._verts
-        nv, nf, over = c.read_counts(ws, with_flags=True)
+        nv, nf, over = self._call.read_counts()
         # bit 1: a vertex region numbered more than 2^26 vertices, its ids are ambiguous.  Not raised HERE: the other
         # ranks would go on into the collectives and hang -- the orchestration spreads the flag to all ranks first
         # (SlabExtractor.extract) and every rank raises.
@@ -110,7 +111,7 @@ class HipBackend:
         overflow = nv > verts.shape[0] or (over & 1)
         if overflow:
             verts = torch.empty((nv, 3), dtype=torch.float32, device=self.device)
-            c.emit(grid, thresh, lower, upper, ws, verts, None, slab=self._slab, full_res=full_res)
+            self._call.emit(self._slab, verts, None)
         self._cap = nv + nv // 8 + 4096
         self._state = (grid, thresh, lower, upper, full_res, ws, nf)
         return nv, nf, verts[:nv], overflow
@@ -140,8 +141,7 @@ class HipBackend:
             faces = self._emit_faces((0, 0, rank_counts, rank))
         else:
             faces = torch.empty((capf, 3), dtype=torch.int32, device=self.device)
-            c.extract_fused_raw(grid, thresh, lower, upper, ws, self._verts, faces,
-                                slab=self._mk(5, 0, 0, 0, rank_counts, rank), full_res=full_res, scratch=self._scratch)
+            self._call.fused(self._mk(5, 0, 0, 0, rank_counts, rank), self._verts, self._scratch, faces)
             nv, nf, verts, overflow = self._read_totals()
             self._scratch = None
             self._copy_pending = False
@@ -149,8 +149,7 @@ class HipBackend:
                 pass   # (the caller raises; the ids are ambiguous, nothing to re-emit)
             elif nf > capf:
                 faces = torch.empty((nf, 3), dtype=torch.int32, device=self.device)
-                c.emit(grid, thresh, lower, upper, ws, None, faces, slab=self._mk(0, 0, 0, 0, rank_counts, rank),
-                       full_res=full_res)
+                self._call.emit(self._mk(0, 0, 0, 0, rank_counts, rank), None, faces)
             else:
                 faces = faces[:nf] if 2 * nf >= capf else faces[:nf].clone()
         self._capf = nf + nf // 8 + 4096
@@ -161,16 +160,13 @@ class HipBackend:
         return self.finalize()
 
     def _plane_view(self, plane):
-        grid, ws = self._state[0], self._state[5]
-        ptr, nbytes = self.capi.plane_records(ws, *grid.shape, plane)
-        off = ptr - ws.data_ptr()
-        return ws[off:off + nbytes]
+        ws = self._state[5]
+        off = self._rec0_off + plane * self._plane_bytes   # (records of plane p: p3d_mc_plane_records; planes are back to back)
+        return ws[off:off + self._plane_bytes]
 
     def export_first_plane_records(self):
-        grid, ws = self._state[0], self._state[5]
-        _, nbytes = self.capi.plane_records(ws, *grid.shape, 0)
-        out = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        return self.capi.export_plane_records(ws, *grid.shape, 0, out)
+        out = torch.empty(self._plane_bytes, dtype=torch.uint8, device=self.device)
+        return self._call.export_plane_records(0, out)
 
     def halo_records_buffer(self):
         return self._plane_view(self._state[0].shape[0] - 1)
@@ -181,13 +177,11 @@ class HipBackend:
         grid, thresh, lower, upper, full_res, ws, nf = self._state
         faces = torch.empty((nf, 3), dtype=torch.int32, device=self.device)
         if self._copy_pending:
-            self.capi.extract_fused_raw(grid, thresh, lower, upper, ws, self._verts, faces,
-                                        slab=self._mk(5, 0, *slab_args), full_res=full_res, scratch=self._scratch)
+            self._call.fused(self._mk(5, 0, *slab_args), self._verts, self._scratch, faces)
             self._copy_pending = False
             self._scratch = None
         else:
-            self.capi.emit(grid, thresh, lower, upper, ws, None, faces, slab=self._mk(0, 0, *slab_args),
-                           full_res=full_res)
+            self._call.emit(self._mk(0, 0, *slab_args), None, faces)
         return faces
 
     def faces(self, vertex_id_base, halo_vertex_id_base):
@@ -327,10 +321,11 @@ class SlabExtractor:
                 elif not ev.query():
                     return
                 state["done"] = True
-                bad = [r for r in range(host.shape[0]) if int(host[r, 2]) & 2]
+                rows = host.tolist()   # (one conversion: indexing a tensor element by element is microseconds each)
+                bad = [r for r, row in enumerate(rows) if row[2] & 2]
                 if bad:
                     state["error"] = OverflowError(self.ID_OVERFLOW % bad)
-                elif int(host[:, 0].sum()) > 2 ** 31 - 1:
+                elif sum(row[0] for row in rows) > 2 ** 31 - 1:
                     state["error"] = OverflowError("global vertex count exceeds int32 face indices")
             if state["error"] is not None:
                 raise state["error"]
