@@ -108,6 +108,9 @@ typedef struct p3d_mc_slab {
     int32_t rank_counts_stride;  /* int64 elements between two ranks' counts (0 = 1): the multi-GPU wrapper all-gathers
                                     the first three header words of every rank's workspace (V, -, flags), so that every
                                     rank also learns every rank's overflow flags; the counts are then 3 apart */
+    void* export_first_plane_to; /* part 3 only, optional DEVICE buffer of bytes_per_plane bytes (p3d_mc_plane_records): the
+                                    dense vertex-id records of local plane 0 are written there by the launch that writes
+                                    the header -- what p3d_mc_export_plane_records does as a launch of its own */
 } p3d_mc_slab;
 
 /* Bytes of device scratch p3d_mc_count / p3d_mc_emit need for an [rx,ry,rz] grid.

@@ -894,27 +894,45 @@ __global__ void __launch_bounds__(kBlock) k_face_total(const u32* __restrict__ c
 // path wants them before the face count: the all-gather of V and the export of the first plane's records can then
 // travel while the counting and compaction kernels run.  (The finishing block of the k_faces launch writes the
 // same values again and reports to the host.)
-__global__ void k_early_header(u64* __restrict__ hdr, const u64* __restrict__ cursors, u32 rows_per_region,
-                               u32 id_limit) {
-    const int lane = threadIdx.x;
-    const u64 cur = lane < kRegions ? cursors[lane * kCursorStride] : 0ull;
-    u64 inc = cur;
+// With `out` the same launch also exports one plane's vertex-id records in dense form (p3d_mc_slab.export_first_plane_to:
+// what p3d_mc_export_plane_records does as a launch of its own; a one-wave kernel behind another one-wave kernel costs the
+// stream 4-5 us each): every block works the region prefixes out of the cursors for itself, block 0 writes the header.
+__global__ void __launch_bounds__(kBlock) k_early_header(u64* __restrict__ hdr, const u64* __restrict__ cursors, u32 rows_per_region,
+                                                         u32 id_limit, const uint2* __restrict__ rec, int64_t first, int64_t n,
+                                                         uint2* __restrict__ out) {
+    __shared__ u32 s_pre[kRegions];
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 64) {
+        const u64 cur = lane < kRegions ? cursors[lane * kCursorStride] : 0ull;
+        u64 inc = cur;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const u64 tt = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += tt;
+        for (int o = 1; o < 64; o <<= 1) {
+            const u64 tt = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += tt;
+        }
+        if (lane < kRegions) s_pre[lane] = (u32)(inc - cur);
+        if (blockIdx.x == 0) {
+            const u64 over = __ballot(cur > (u64)rows_per_region);
+            const u64 wrap = __ballot(cur > (u64)id_limit);
+            if (lane < kRegions) hdr[H_PREFIX + lane] = inc - cur;
+            // (the cursors come from the stream's ring of pre-cleared blocks: the later parts of the extraction find the region
+            //  counts in the workspace header)
+            if (lane < kRegions && cursors != hdr + H_CURSORS) hdr[H_CURSORS + lane * kCursorStride] = cur;
+            if (lane == kRegions - 1) {
+                hdr[H_V] = inc;
+                hdr[H_FLAGS] = (over ? 1ull : 0ull) | (wrap ? 2ull : 0ull);
+                hdr[H_RECFORM] = 1ull;
+            }
+        }
     }
-    const u64 over = __ballot(cur > (u64)rows_per_region);
-    const u64 wrap = __ballot(cur > (u64)id_limit);
-    if (lane < kRegions) hdr[H_PREFIX + lane] = inc - cur;
-    // (the cursors of a slab streamed in ONE call come from the stream's ring of pre-cleared blocks, like a whole grid's: the
-    //  later parts of the extraction find the region counts in the workspace header)
-    if (lane < kRegions && cursors != hdr + H_CURSORS) hdr[H_CURSORS + lane * kCursorStride] = cur;
-    if (lane == kRegions - 1) {
-        hdr[H_V] = inc;
-        hdr[H_FLAGS] = (over ? 1ull : 0ull) | (wrap ? 2ull : 0ull);
-        hdr[H_RECFORM] = 1ull;
-    }
+    if (!out) return;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    uint2 r = rec[first + i];   // (fresh from the streaming kernel: region form)
+    const u32 reg = r.x >> 26;
+    if (reg < (u32)kRegions) r.x = (r.x & 0x3ffffffu) + s_pre[reg];
+    out[i] = r;
 }
 
 __global__ void __launch_bounds__(kBlock) k_zero_words(u64* __restrict__ p, int64_t n) {
@@ -1550,19 +1568,29 @@ const Tuning& tuning() {
 // call n uses block n % kCursorRing and its streaming kernel clears block (n + 1) % kCursorRing, whose last user ran
 // kCursorRing - 1 calls earlier on the same stream (stream order makes that safe).  A slab streamed in two parts
 // keeps its block for the second part.
-constexpr int kCursorRing = 4;
+constexpr int kCursorRing = 16;   // (an extraction in several calls keeps its block while up to 13 others start on the stream)
 constexpr int kRingSlotWords = kCursorBlockWords;   // the 32 cursors of one call
 struct CursorRing {
     int dev = -1;
     hipStream_t stream = nullptr;
     u64* base = nullptr;
     int cur = 0;
+    uint64_t gen = 0;   // blocks handed out so far (a continuing part checks that its block has not come round again)
     std::mutex mu;   // held by a call from the moment it takes its block until its LAST kernel is enqueued
 };
 // (device, stream) -> ring.  shared_ptr: a call's lease keeps its ring alive while p3d_mc_release_stream / p3d_mc_shutdown
 // on another thread takes it out of the map.
 std::mutex g_ring_mu;
 std::map<std::pair<int, hipStream_t>, std::shared_ptr<CursorRing>> g_rings;
+
+// The cursor block an extraction in several calls took with its first part (part 1): the parts that continue the streaming
+// (2, 3) use the same block; kept in the workspace's entry of the protocol table.
+struct HeldBlock {
+    u64* cursors = nullptr;               // null: the extraction keeps its cursors in its workspace header
+    std::shared_ptr<CursorRing> ring;
+    u64* ring_base = nullptr;             // the ring's allocation when the block was taken (a released ring is gone)
+    uint64_t gen = 0;                     // ring->gen right after the block was taken
+};
 
 // A call's hold on its stream's ring.  Two host threads may share one stream (through ctypes the GIL is released): the
 // block a call uses is cleared by the streaming kernel of the call BEFORE it in ring order, and is read by all three of
@@ -1577,7 +1605,12 @@ struct RingLease {
     // clears the next one.  A call that fails between taking its block and that launch (a HIP error, the dev-build hook
     // P3D_TEST_FAIL_AFTER_LEASE) leaves the ring where it was: the next call takes the same, still clean block, and the
     // block after it is still waiting for a clearing kernel that will now be that call's.
-    void commit() { if (ring) ring->cur = next; }
+    void commit() {
+        if (ring) {
+            ring->cur = next;
+            ++ring->gen;
+        }
+    }
 };
 
 // the next block of the stream's ring (and the one after it in *zero_next, to be cleared by this call's kernel); the caller
@@ -1973,7 +2006,7 @@ Xform make_xform(const Dims& d, const float lower[3], const float upper[3], cons
 template <typename T>
 int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xform& t, const p3d_mc_slab* slab,
                char* ws, float* verts, int64_t capv, float* scratch, int64_t scratch_rows, int32_t* faces,
-               int64_t capf, hipStream_t st) {
+               int64_t capf, hipStream_t st, HeldBlock* held) {
     const int halo = slab ? slab->halo_last_plane : 0;
     u64* hdr = (u64*)(ws + w.hdr);
     u64* bits = (u64*)(ws + w.bits);
@@ -1996,21 +2029,29 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     int x_lo = 0, x_hi = (int)d.rx;
     if (part == 1) x_hi = (int)slab->split_plane;
     if (part == 2 || part == 3) x_lo = (int)slab->split_plane;
-    // The 32 output cursors: a whole-grid call takes a pre-cleared block from the per-stream ring (no fill kernel).  An
-    // extraction made of several calls keeps them inside its own workspace header instead, cleared by its first part:
-    // other extractions may run on the same stream in between (the in-process multi-rank harness does exactly that).
+    // The 32 output cursors: every call that STARTS streaming takes a pre-cleared block from the per-stream ring (no fill
+    // kernel).  A call that continues the streaming of an extraction (part 2, or part 3 behind part 1) uses the block part 1
+    // took -- remembered in the workspace's entry of the protocol table; other extractions may start on the stream in
+    // between (the in-process multi-rank harness does exactly that), each taking the next block: the held block stays
+    // untouched until the ring has come round, which is checked.  The parts behind the streaming (4, 5, 6) find the region
+    // counts in the workspace header (k_early_header / the finishing block copy them there).
     u64 *cursors = nullptr, *zero_next = nullptr;
     RingLease lease;   // (released when this function returns: every launch of the call is enqueued by then)
     const bool new_block = part == 0 || part == 1 || (part == 3 && slab->split_plane == 0);
-    // (part 3 from plane 0 streams the whole slab in this one call: a ring block serves it too, and k_early_header leaves the
-    //  region counts in the workspace header for the parts that follow -- no clearing kernel in front of the streaming kernel)
-    const bool ring_block = part == 0 || (part == 3 && slab->split_plane == 0 && tuning().parts_ring != 0);   // (P3D_PARTS_RING=0: dev A/B)
+    const bool ring_block = part == 0 || (new_block && tuning().parts_ring != 0);   // (P3D_PARTS_RING=0: dev A/B, header cursors)
+    const bool continues = (part == 2 || (part == 3 && slab->split_plane != 0)) && held && held->cursors;
     if (ring_block) {
         if (int rc = cursor_block_for(st, &lease, &cursors, &zero_next)) return rc;
 #if P3D_DEV_HOOKS
         if (g_fail_after_lease.load() > 0 && g_fail_after_lease.fetch_sub(1) > 0)
             return fail(P3D_EHIP, "injected failure between the cursor lease and the first launch (P3D_TEST_FAIL_AFTER_LEASE)%s");
 #endif
+    } else if (continues) {
+        std::lock_guard<std::mutex> g(held->ring->mu);
+        if (held->ring->base != held->ring_base || held->ring->gen - held->gen > (uint64_t)(kCursorRing - 3))
+            return fail(P3D_EINVAL, "the cursor block part 1 took is gone: the stream's state was released, or more than 13 other "
+                                    "extractions started on the stream since%s");
+        cursors = held->cursors;
     } else {
         cursors = hdr + H_CURSORS;
         if (new_block)   // (an ordinary kernel: the runtime's fill path starts late, see fused_stack_impl)
@@ -2029,10 +2070,19 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         // (a launch that was refused never ran: the ring stays where it was)
         HIP_TRY(hipGetLastError());
         lease.commit();
+        if (held && ring_block && part == 1) {   // the parts that continue the streaming find the block through the table
+            held->cursors = cursors;
+            held->ring = lease.ring;
+            held->ring_base = lease.ring->base;
+            held->gen = lease.ring->gen;
+        }
     }
-    if (part == 3)
-        hipLaunchKernelGGL(k_early_header, dim3(1), dim3(64), 0, st, hdr, cursors, scratch ? store_rows : region_rows,
-                           id_limit);
+    if (part == 3) {
+        // (p3d_mc_slab.export_first_plane_to: the dense records of plane 0 for the previous rank, in the same launch)
+        uint2* const exp = (uint2*)slab->export_first_plane_to;
+        hipLaunchKernelGGL(k_early_header, dim3(exp ? (u32)((d.P + kBlock - 1) / kBlock) : 1u), dim3(exp ? kBlock : 64), 0, st, hdr,
+                           cursors, scratch ? store_rows : region_rows, id_limit, (const uint2*)rec, (int64_t)0, d.P, exp);
+    }
     if (part == 1 || part == 3) {  // a later call finalizes
         HIP_TRY(hipGetLastError());
         return P3D_OK;
@@ -2160,6 +2210,7 @@ struct Extraction {
     int64_t scratch_rows = 0;
     const float* verts4 = nullptr;   // the vertex buffer part 4 began to fill (null: it copied nothing)
     int64_t capv4 = 0;
+    HeldBlock held;                  // part 1's cursor block, for the parts that continue the streaming
     uint64_t last_use = 0;
 };
 constexpr size_t kMaxExtractions = 1024;
@@ -2384,9 +2435,9 @@ int p3d_mc_extract_fused(const void* grid, int dtype, int64_t rx, int64_t ry, in
         return rc;
     const int rc = dtype == P3D_F32
                        ? fused_impl((const float*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices, vertex_scratch,
-                                    scratch_rows, faces, cap_faces, st)
+                                    scratch_rows, faces, cap_faces, st, &next.held)
                        : fused_impl((const __half*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices,
-                                    vertex_scratch, scratch_rows, faces, cap_faces, st);
+                                    vertex_scratch, scratch_rows, faces, cap_faces, st, &next.held);
     if (rc == P3D_OK) proto_commit(ws, next);
     return rc;
 }

@@ -80,7 +80,12 @@ class HipBackend:
         split = getattr(self, "_split", 0)
         if not split:
             self._prepare(grid, x_origin, halo, thresh, lower, upper, full_res)
-        self._call.fused(self._mk(3, split), self._verts, self._scratch, None)
+        slab = self._mk(3, split)
+        self._exported = None
+        if getattr(self, "export_first_plane", False):   # (rank > 0: the previous rank's halo records, in the header's launch)
+            self._exported = torch.empty(self._plane_bytes, dtype=torch.uint8, device=self.device)
+            slab.export_first_plane_to = self._exported.data_ptr()
+        self._call.fused(slab, self._verts, self._scratch, None)
         self._state = (grid, thresh, lower, upper, full_res, self._ws, None)
 
     def header_vertex_count(self):
@@ -165,6 +170,8 @@ class HipBackend:
         return ws[off:off + self._plane_bytes]
 
     def export_first_plane_records(self):
+        if getattr(self, "_exported", None) is not None:   # (written by part 3's header launch)
+            return self._exported
         out = torch.empty(self._plane_bytes, dtype=torch.uint8, device=self.device)
         return self._call.export_plane_records(0, out)
 
@@ -238,6 +245,8 @@ class SlabExtractor:
         rx, ry, rz = self.shape
         self.grid = torch.empty((self.n + (1 if self.has_halo else 0), ry, rz), dtype=dtype, device=device)
         self.backend = backend if backend is not None else HipBackend(device)
+        if rank > 0 and hasattr(self.backend, "stream_rest"):
+            self.backend.export_first_plane = True   # part 3 writes plane 0's dense records with the header (one launch)
         # phase tracing (bench.py --stages): events on the current stream at the phase boundaries of extract(); the
         # span between two marks is the GPU time of what was enqueued between them, waits on collectives included
         self.trace = False

@@ -196,7 +196,7 @@ def test_the_cursor_ring_survives_a_call_that_fails_after_its_lease(gpu, built, 
     from primitive3d_amd.fields import perlin_grid
     g = perlin_grid((48, 40, 130), period=14, seed=9).to(gpu)
     ref = oracle_count(g.cpu().numpy(), 0.0)
-    for _ in range(5):   # every block of the ring has been used (dirty unless cleared by the call before)
+    for _ in range(20):   # every block of the ring (16) has been used (dirty unless cleared by the call before)
         v, f = built.marching_cubes(g, 0.0)
         assert (v.shape[0], f.shape[0]) == ref
     for fails in (1, 3):
@@ -204,7 +204,7 @@ def test_the_cursor_ring_survives_a_call_that_fails_after_its_lease(gpu, built, 
         for _ in range(fails):
             with pytest.raises(RuntimeError, match="injected failure"):
                 built.marching_cubes(g, 0.0)
-        for _ in range(6):   # more than a whole turn of the ring
+        for _ in range(20):   # more than a whole turn of the ring
             v, f, k = None, None, None
             v, f = built.marching_cubes(g, 0.0)
             assert (v.shape[0], f.shape[0]) == ref
@@ -229,4 +229,27 @@ def test_the_table_holds_the_most_recent_workspaces(gpu):
     r.refuse(lambda: r.call(4, ws=pool[0]), "none is in progress")
     r.call(4, ws=pool[-1])          # the most recent ones are all there
     r.call(4, ws=pool[-500])
+    torch.cuda.synchronize()
+
+
+def test_part_1_keeps_its_cursor_block_while_others_start_on_the_stream(gpu):
+    """Part 1 takes a pre-cleared block of the stream's ring (no clearing kernel) and the parts that continue the streaming
+    use the same block; up to 13 other extractions may start on the stream in between -- each takes the next block --, as
+    the in-process multi-rank harness does.  More than that and the block has come round: refused, never garbage."""
+    r = Rig(gpu)
+    other = Rig(gpu, shape=(12, 16, 70), seed=8)
+    split = 16
+    r.call(1, split=split, v=r.v)
+    for _ in range(13):
+        other.call(0, v=other.v, f=other.f)
+    r.call(3, split=split, v=r.v)
+    r.call(4, v=r.v)
+    assert r.capi.read_counts(r.ws) == (r.nv, r.nf)
+    r.call(5, v=r.v, f=r.f)
+    _mesh_ok(r, r.v, r.f)
+    r.fresh().call(1, split=split, v=r.v)
+    for _ in range(14):
+        other.call(0, v=other.v, f=other.f)
+    with pytest.raises(r.capi.P3DError, match="cursor block part 1 took is gone"):
+        r.call(2, split=split, v=r.v, f=r.f)
     torch.cuda.synchronize()
