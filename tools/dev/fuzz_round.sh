@@ -6,6 +6,5 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; N=${2:-150}; mkdir -p $O; cd $R
   SEED=41 N=40 RZ=2040,2300 python tools/dev/fuzz_parity.py
   for s in 51 52; do SEED=$s N=60 python tools/dev/fuzz_batched.py; done
   for s in 61 62; do SEED=$s N=60 python tools/dev/fuzz_slabs.py; done
-  for s in 71 72; do SEED=$s N=25 python tools/dev/fuzz_dyn.py; done
   python tools/dev/odd_shapes.py
   python tools/dev/odd_fields.py ) 2>&1 | grep -v "amdgpu.ids" | tee $O/fuzz.txt | tail -40
