@@ -253,3 +253,40 @@ def test_part_1_keeps_its_cursor_block_while_others_start_on_the_stream(gpu):
     with pytest.raises(r.capi.P3DError, match="cursor block part 1 took is gone"):
         r.call(2, split=split, v=r.v, f=r.f)
     torch.cuda.synchronize()
+
+
+def test_part_3_exports_the_first_planes_records_with_the_header(gpu):
+    """p3d_mc_slab.export_first_plane_to: the launch that writes the header also writes plane 0's dense vertex-id records --
+    the same bytes p3d_mc_export_plane_records gives as a launch of its own."""
+    r = Rig(gpu)
+    _, nbytes = r.capi.plane_records(r.ws, *r.shape, 0)
+    out = torch.zeros(nbytes, dtype=torch.uint8, device=gpu)
+    slab = r.capi.Slab()
+    slab.part, slab.export_first_plane_to = 3, out.data_ptr()
+    r.capi.extract_fused_raw(r.g, 0.0, r.lower, r.upper, r.ws, None, None, slab=slab, scratch=r.scratch)
+    ref = r.capi.export_plane_records(r.ws, *r.shape, 0, torch.zeros_like(out))
+    torch.cuda.synchronize()
+    # (records of units without vertices hold garbage in both: compare the units that own vertices)
+    a, b = out.view(torch.int32).view(-1, 2).cpu(), ref.view(torch.int32).view(-1, 2).cpu()
+    owns = (b[:, 1] != 0) | (a[:, 1] != 0)
+    bits_off = r.capi.debug_layout(*r.shape)
+    assert owns.any()
+    assert torch.equal(a[owns], b[owns])
+
+
+def test_rank_counts_serve_64_ranks(gpu):
+    r = Rig(gpu)
+    rc = torch.zeros(80, dtype=torch.int64, device=gpu)
+    r.call(3)
+    r.call(4)
+    slab = r.capi.Slab()
+    slab.part, slab.rank_counts, slab.rank = 6, rc.data_ptr(), 64
+    with pytest.raises(r.capi.P3DError, match="ranks 0..63"):
+        r.capi.extract_fused_raw(r.g, 0.0, r.lower, r.upper, r.ws, r.v, r.f, slab=slab, scratch=r.scratch)
+    # rank 63 with made-up counts of the ranks before it: the ids are shifted by their sum
+    rc[:63] = 1000
+    rc[63] = r.nv
+    slab.rank = 63
+    r.capi.extract_fused_raw(r.g, 0.0, r.lower, r.upper, r.ws, r.v, r.f, slab=slab, scratch=r.scratch)
+    torch.cuda.synchronize()
+    assert int(r.f.min()) == 63000 and int(r.f.max()) == 63000 + r.nv - 1
