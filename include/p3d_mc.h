@@ -86,7 +86,9 @@ typedef struct p3d_mc_slab {
                                 CHECKS the order (per workspace; host side, before anything is launched) and returns
                                 P3D_EINVAL with a message for every successor this table does not have:
                                      call                      legal after (on the same workspace)
-                                     0, 1, 3 with split 0      anything (starts a new extraction)
+                                     0, 1, 3 with split 0      anything (starts a new extraction; each takes the next of the
+                                                               stream's 16 pre-cleared cursor blocks -- part 1 keeps its
+                                                               block for parts 2 / 3 while up to 13 others start)
                                      2                         1 (same split_plane)
                                      3 with split_plane > 0    1 (same split_plane)
                                      4                         3
@@ -241,7 +243,7 @@ int p3d_mc_dev_hooks(void);
 
 /* Library-owned state (no reference counterpart: the reference keeps none, marching_cubes.cu:229-230 allocates its four
  * counters per call).  Per (device, stream) the library keeps a ring of pre-cleared blocks (cursors of the streaming
- * kernel, 16 KiB) and per device a 4 KiB pinned mailbox; both are created on first use.
+ * kernel: sixteen 4 KiB blocks) and per device a 4 KiB pinned mailbox; both are created on first use.
  *   p3d_mc_release_stream: frees what is kept for `stream` on the CURRENT device, after waiting for the work queued on it.
  *       Call it before destroying a stream the library was used on; a later call on that stream simply creates the state
  *       again.  Unknown streams are fine (returns 0).

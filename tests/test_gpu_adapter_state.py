@@ -86,7 +86,7 @@ def _hip():
 def test_release_stream_keeps_device_memory_flat(gpu, built):
     """A C caller that creates a stream per job: 1000 streams, one extraction on each, p3d_mc_release_stream before the
     stream is destroyed -> the library keeps no ring for it any more (p3d_mc_debug_counters: `stream_rings`; a ring is
-    16 KiB of device memory since round 5, 0.5 MiB before).  Without the release the rings stay (that is what the entry
+    64 KiB of device memory since round 5, 2 MiB before).  Without the release the rings stay (that is what the entry
     point is for)."""
     from primitive3d_amd import capi
     hip = _hip()
