@@ -88,6 +88,29 @@ def test_c3_whole_mesh_equals_the_oracle(gpu, built):
     assert np.array_equal(a, np.sort(rv.view([("", np.float32)] * 3), axis=0))
 
 
+def test_c3_fresh_grids_in_turn(gpu, built):
+    """bench.py's `modes.fresh_grid` workload at its full size: four distinct 512^3 grids (seeds 0..3) taken in turn through
+    the boundary call -- every call's counts against the independent count, closed-manifold properties, and the meshes of
+    the second turn equal to the first turn's (the size hints come from the OTHER grids' calls: every call is one pass)."""
+    from primitive3d_amd import capi
+    from primitive3d_amd.fields import perlin_grid
+    grids = [perlin_grid(512, period=64, seed=sd, device=gpu) for sd in range(4)]
+    want = [torch_counts(g, 0.0) for g in grids]
+    assert len(set(want)) == 4
+    first = []
+    for turn in range(2):
+        for i, g in enumerate(grids):
+            p0 = capi.debug_counters()["streaming_passes"]
+            v, f = built.libPrim3D.marching_cubes(g, 0.0, [0.0] * 3, [512.0] * 3)
+            assert (v.shape[0], f.shape[0]) == want[i], (turn, i)
+            if turn == 0:
+                mesh_properties(v, f)
+                first.append(soup_hashes(v, f))
+            else:
+                assert capi.debug_counters()["streaming_passes"] - p0 == 1, (turn, i)
+                assert torch.equal(soup_hashes(v, f), first[i]), (turn, i)
+
+
 def test_c3_four_octave_field_whole_mesh(gpu, built):
     """SURVEY.md 8d, C3's secondary workload at full size: four octaves (period 64 -> 8, persistence 0.5), about twice the
     surface of the single-octave field and much finer detail (more vertices per wave-plane, denser face tiles).  Whole mesh
