@@ -7,7 +7,7 @@ for ((i = 0; i < reps; i++)); do
   for spec in "$@"; do
     IFS='|' read -r label envs cmd <<< "$spec"
     out=$(env $envs python $cmd 2>/dev/null | tail -1)
-    for k in k_fused k_face_count_walk k_faces; do
+    for k in k_fused k_face_count_walk k_faces k_sum; do
       v=$(echo "$out" | grep -o "'$k': [0-9.]*" | grep -o "[0-9.]*$")
       acc["$label $k"]+="$v "
     done
