@@ -63,6 +63,7 @@ def test_default_run_reports_the_other_configs(gpu):
     # SlabExtractor.extract() with the transport stubbed, and what the 8-GPU run can reach at most without it
     rs = oc["c4_rank_slab"]
     assert rs["predicted_speedup_8gpu_no_transport"] == pytest.approx(oc["c4_1gpu"]["ms_per_step"] / rs["ms_per_step"], abs=0.01)
+    assert 0 < rs["ms_per_step_without_standin_copies"] and rs["predicted_speedup_8gpu_without_standin_copies"] > 0
     assert 0.09 * oc["c4_1gpu"]["vertices"] < rs["vertices"] < 0.16 * oc["c4_1gpu"]["vertices"]   # an eighth of the surface
     assert "faces + rest of vertex copy" in rs["phases_ms_last_step"]
     assert oc["c5"]["dtype"] == "f16" and oc["c2"]["dtype"] == "f32"
