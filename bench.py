@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the marching-cubes hot path (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU; started
+                                                         WITHOUT a rank environment it starts those ranks itself as a child
+                                                         `python -m torch.distributed.run ... bench.py` and relays its result)
 
 A "step" is one whole call of the drop-in boundary (`libPrim3D.marching_cubes`: classify+count ->
 host read of V,F -> allocation -> vertex + face emission incl. the scale/offset epilogue) on a
@@ -14,6 +16,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline`
 kernel (hipEvent-timed inside the library, on the launch stream) and `cpu_baseline` (the CPU oracle
 restatement of the reference kernels on all host cores and on one thread, an `import mcubes` attempt, and the
 whole-mesh comparison with the GPU's result; N=1 only).  `--config c2|c4|c5` selects the other single-GPU workloads.
+The N>1 line also carries what RCCL saw (`config.rccl`: backend, world size, every rank's device) and, measured by rank 0
+in the same run outside the timed region, the same whole volume through the plain single-GPU call (`full_volume_1gpu`,
+`speedup_vs_1gpu`; at N=8 also `c4_1gpu_ms` / `speedup_vs_1gpu_1024`: the north-star's ">= 6x at 8 GPUs on 1024^3").
 """
 import argparse
 import json
@@ -484,6 +489,27 @@ def measure_modes(p3d, capi, grid, lower, upper, perlin_grid):
     return out
 
 
+def self_launch(gpus):
+    """`python3 bench.py --gpus N` with no rank environment: this process -- which has made no GPU call and makes none --
+    starts the N ranks the way the driver would (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py <the same arguments>`) as a CHILD process, lets rank 0's JSON line and
+    the ranks' stderr through (inherited descriptors) and exits with the launcher's return code.  Never os.exec*: a
+    process that touched the GPU must not be replaced by another, and this one must stay around to report the code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:   # (a free port of the loopback interface; the container's host name may not resolve)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), *sys.argv[1:]]
+    sys.stderr.write("bench.py: no WORLD_SIZE in the environment -- starting the ranks: " + " ".join(cmd) + "\n")
+    sys.stderr.flush()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if os.environ.get("P3D_BENCH_LAUNCH_DRY") == "1":   # (tests without a GPU: say what would be started, start nothing)
+        return 0
+    return subprocess.call(cmd, env=env, cwd=str(ROOT))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -510,6 +536,8 @@ def main():
         return child_stream(args.steps, args.warmup)
     if args.child == "fresh":
         return child_fresh(args.steps, args.warmup)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus))   # (before anything touches the GPU: torch is not even imported yet)
 
     import torch
     import torch.distributed as dist
@@ -518,8 +546,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         sys.exit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: they must agree")
     # dev-only overrides to dry-run the N>1 code path on a 1-GPU box: all ranks on cuda:0, gloo transport
     share = os.environ.get("P3D_BENCH_SHARE_DEVICE") == "1"
@@ -650,6 +676,36 @@ def main():
         torch.cuda.synchronize()
         call_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
 
+    # N > 1: what RCCL saw (ranks, their devices), and -- on rank 0, after and outside the timed region, while the other
+    # ranks wait at the barrier -- the SAME whole volume through the plain single-GPU call: the denominator of the
+    # north-star's ">= 6x at 8 GPUs on 1024^3" measured in the same run, on the same box
+    rccl_seen = full_1gpu = None
+    if world > 1:
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(),
+                                      "name": torch.cuda.get_device_name(dev)})
+        rccl_seen = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                     "devices": [d["device"] for d in sorted(seen, key=lambda d: d["rank"])],
+                     "device_names": sorted(set(d["name"] for d in seen))}
+        if rank == 0:
+            try:
+                gfull = perlin_grid(shape, period=64, seed=0, device=dev)
+                n1 = 4
+                for _ in range(2):
+                    fv, ff = p3d.libPrim3D.marching_cubes(gfull, thresh, lower, upper)
+                torch.cuda.synchronize()
+                c0 = time.perf_counter()
+                for _ in range(n1):
+                    fv, ff = p3d.libPrim3D.marching_cubes(gfull, thresh, lower, upper)
+                torch.cuda.synchronize()
+                full_1gpu = {"ms_per_step": (time.perf_counter() - c0) / n1 * 1e3, "steps": n1,
+                             "vertices": int(fv.shape[0]), "faces": int(ff.shape[0])}
+                del gfull, fv, ff
+                torch.cuda.empty_cache()
+            except Exception as e:   # (the line must not depend on it: e.g. no room for the whole volume)
+                full_1gpu = {"error": f"{type(e).__name__}: {e}"[:300]}
+        barrier()
+
     elapsed = t1 - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -721,6 +777,22 @@ def main():
                        "partition": "none" if world == 1 else f"axis-0 slabs x{world}, 1-plane RCCL halo"},
             "roofline": roofline,
         }
+        if world > 1:
+            # "RCCL saw N ranks": the process group's own view (backend, world size, the device of every rank)
+            line["config"]["rccl"] = rccl_seen
+            line["config"]["parallelism"] = f"slab{world}"
+            if full_1gpu and "error" not in full_1gpu:
+                one = full_1gpu["ms_per_step"]
+                line["full_volume_1gpu"] = {**full_1gpu, "ms_per_step": round(one, 4),
+                                            "workload": f"the same {rx}x{ry}x{rz} volume through the plain single-GPU call on "
+                                                        "rank 0's GPU, same run, after the timed region (the other ranks wait)",
+                                            "meshes_agree": (full_1gpu["vertices"], full_1gpu["faces"]) == (nv, nf)}
+                line["speedup_vs_1gpu"] = round(one / ms_per_step, 3)
+                if (rx, ry, rz) == (1024, 1024, 1024):   # BASELINE.json configs[3]: the >= 6x target is this one field
+                    line["c4_1gpu_ms"] = round(one, 4)
+                    line["speedup_vs_1gpu_1024"] = round(one / ms_per_step, 3)
+            elif full_1gpu:
+                line["full_volume_1gpu"] = full_1gpu
         if world == 1 and args.config == "c3" and not args.size and not args.no_modes:
             line["modes"] = measure_modes(p3d, capi, grid, lower, upper, perlin_grid)
             fg = line["modes"].get("fresh_grid", {})

@@ -236,6 +236,13 @@ class SlabExtractor:
     def __init__(self, shape: Sequence[int], rank: int, world: int, device, dtype=torch.float32, backend=None,
                  hold_planes: int = 2):
         self.shape = tuple(int(s) for s in shape)
+        # the device path derives a slab's id bases from the gathered counts with one lane of a wave per rank
+        # (include/p3d_mc.h: p3d_mc_slab.rank_counts serves ranks 0..63).  Refused HERE, on every rank alike and before any
+        # collective: the C ABI would refuse ranks >= 64 only inside finish_on_device, after the all-gather and the record
+        # exchange were enqueued, and the ranks below 64 would wait for them in the next collective for ever.
+        if world > 64 and (backend is None or hasattr(backend, "faces_from_rank_counts")):
+            raise ValueError(f"SlabExtractor serves at most 64 ranks on the device path (world = {world}): "
+                             "use fewer, thicker slabs")
         self.hold_planes = max(1, int(hold_planes))   # local planes kept back for the launch that needs the halo plane
         self.rank, self.world = rank, world
         self.device = device

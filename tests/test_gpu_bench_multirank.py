@@ -24,14 +24,22 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,size", [(2, 128), (8, 64)])
-def test_bench_gpus_n_dry_run(gpu, built, world, size):
+@pytest.mark.parametrize("world,size,launcher", [(2, 128, "driver"), (8, 64, "driver"), (2, 96, "self")])
+def test_bench_gpus_n_dry_run(gpu, built, world, size, launcher):
+    """launcher "driver": the driver's command line (torch.distributed.run around bench.py); "self": plain
+    `python bench.py --gpus N` with no rank environment -- bench.py starts the ranks itself as a child process and relays
+    rank 0's line and the return code (the first 8-GPU run must not die at argument parsing)."""
     from primitive3d_amd import capi
     from primitive3d_amd.fields import perlin_grid
     env = dict(os.environ, P3D_BENCH_SHARE_DEVICE="1", P3D_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           str(ROOT / "bench.py"), "--gpus", str(world), "--size", str(size), "--steps", "3", "--warmup", "2", "--stages"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    tail = [str(ROOT / "bench.py"), "--gpus", str(world), "--size", str(size), "--steps", "3", "--warmup", "2", "--stages"]
+    if launcher == "driver":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), *tail]
+    else:
+        cmd = [sys.executable, *tail]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
@@ -43,6 +51,12 @@ def test_bench_gpus_n_dry_run(gpu, built, world, size):
     assert d["config"]["voxels_per_gpu"] == size ** 3 and f"{shape[0]}x{shape[1]}x{shape[2]}" in d["config"]["workload"]
     assert abs(d["value"] - shape[0] * shape[1] * shape[2] / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
     assert "cpu_baseline" not in d and "other_configs" not in d and "modes" not in d
+    # what the process group saw, and the same whole volume on ONE GPU measured by rank 0 in the same run (item 2b, 2d)
+    rc = d["config"]["rccl"]
+    assert rc["world_size"] == world and rc["backend"] == "gloo" and rc["devices"] == [0] * world, rc
+    one = d["full_volume_1gpu"]
+    assert "error" not in one and one["meshes_agree"] is True and one["ms_per_step"] > 0, one
+    assert d["speedup_vs_1gpu"] == pytest.approx(one["ms_per_step"] / d["ms_per_step"], rel=0.01)
     assert d["roofline"]["kernel"] == "k_fused" and d["roofline"]["alg_bytes_per_launch"] == size ** 3 * 4
     # the slabs' meshes add up to the plain call's on the whole field
     g = perlin_grid(shape, period=64, seed=0, device=gpu)
