@@ -144,6 +144,7 @@ def test_slab_bounds():
 def test_more_than_64_ranks_are_refused_before_any_collective():
     """The device path gives one lane of a wave to every rank (p3d_mc_slab.rank_counts: ranks 0..63): a larger world is
     refused in the constructor, on every rank alike, not inside an extraction that other ranks are already waiting in."""
+    from primitive3d_amd.slab import SlabExtractor
     with pytest.raises(ValueError, match="at most 64 ranks"):
         SlabExtractor((130, 4, 70), 3, 65, torch.device("cpu"))
     SlabExtractor((130, 4, 70), 3, 65, torch.device("cpu"), backend=object())   # (a host-path backend: no such limit)
