@@ -42,7 +42,29 @@ def _worker(rank, world, port, out_dir, shape, thresh, lower, upper, backend="gl
     torch.cuda.synchronize()
     res.check_total()  # the deferred int32 guard of the device path
     phases = ex.phase_times_ms()
-    assert "faces + rest of vertex copy" in phases and all(t >= 0 for t in phases.values())
+    assert all(t >= 0 for t in phases.values())
+    # every phase mark of extract()'s device path exists: each line of it that CAN run on this box has run
+    for name in ("interior planes streamed", "halo plane received (wait)", "last planes streamed + record export",
+                 "all-gather of vertex counts", "face count + early vertex copy", "halo records received (wait)",
+                 "faces + rest of vertex copy"):
+        assert name in phases, (name, sorted(phases))
+    if backend == "nccl" and world == 1:
+        # RCCL's point-to-point path itself, on the one GPU: the batched isend / irecv pair extract() posts between
+        # neighbours, with THIS rank as the peer (RCCL runs a grouped send + recv to self), on the very views it hands over
+        # -- a plane of the grid, a plane of vertex-id records inside the workspace -- while a kernel of the caller runs;
+        # then the 24-byte all_gather_into_tensor straight out of the workspace header
+        plane, recs = ex.grid[0], ex.backend._plane_view(0)
+        got_plane, got_recs = torch.zeros_like(plane), torch.zeros_like(recs)
+        works = dist.batch_isend_irecv([dist.P2POp(dist.isend, plane, 0), dist.P2POp(dist.irecv, got_plane, 0),
+                                        dist.P2POp(dist.isend, recs, 0), dist.P2POp(dist.irecv, got_recs, 0)])
+        busy = torch.randn(1024, 1024, device=dev) @ torch.randn(1024, 1024, device=dev)
+        for w in works:
+            w.wait()
+        gathered = torch.empty((world, 3), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(gathered.view(-1), ex.backend.header_words())
+        torch.cuda.synchronize()
+        assert torch.equal(got_plane, plane) and torch.equal(got_recs, recs) and busy.isfinite().all()
+        assert int(gathered[0, 0]) == res.vertices.shape[0]
     lshape = tuple(ex.grid.shape)
     k = vertex_keys_from_workspace(ex.backend._ws.cpu().numpy(), lshape, res.vertices.shape[0],
                                    capi.debug_layout(*lshape), halo_last_plane=ex.has_halo)
@@ -74,7 +96,9 @@ def test_device_path_over_rccl_with_one_rank(tmp_path, gpu, shape):
     spawned child, SlabExtractor.extract() through the DEVICE path -- `all_gather_into_tensor` of the three header words
     straight out of the workspace, the side-stream int32 / overflow guard with its `record_stream`, the face launch
     taking its id bases from the gathered tensor -- twice (the second call takes the size hints), result == the oracle's
-    mesh of the whole grid.  (Two ranks need two GPUs: the test above.)"""
+    mesh of the whole grid; every phase mark of extract() must exist; then RCCL's batched isend / irecv pair with the rank
+    itself as the peer on a grid plane and on a record plane of the workspace (the views extract() posts between
+    neighbours).  (Two ranks need two GPUs: the test above.)"""
     _run_and_compare(tmp_path, 1, shape, "nccl")
 
 
