@@ -394,9 +394,10 @@ def measure_modes(p3d, capi, grid, lower, upper, perlin_grid):
                        still in the memory-side cache when the next call starts (profiles/r04/dyn_ranges.txt section 13:
                        ~10 us of k_fused); a caller streaming new grids sees this number.  `k_fused_ms` by the same
                        dispatch-attached events as `roofline` -> `roofline.frac_fresh`
-      two_phase        the literal binding INTEGRATION.md section 2 shows first: p3d_mc_count -> p3d_mc_read_counts -> allocate
-                       -> p3d_mc_emit (the reference's structure, marching_cubes.cu:242-287, kernel for kernel: a
-                       classification pass, scans, then a gather emitter that reads the field a second time)"""
+      two_phase        the literal pair of INTEGRATION.md section 2: p3d_mc_count -> p3d_mc_read_counts -> allocate ->
+                       p3d_mc_emit (the reference's structure, marching_cubes.cu:242-287).  Since ABI v10 both are the
+                       one-pass kernels: the streaming kernel in count-only form + the face count, then a second streaming
+                       pass that stores every output region at its final rows + the face launch (no scratch, no copy)"""
     import torch
     out = {}
     try:
@@ -480,7 +481,8 @@ def measure_modes(p3d, capi, grid, lower, upper, perlin_grid):
         torch.cuda.synchronize()
         out["two_phase"] = {"ms_per_step": round((time.perf_counter() - t0) / 8 * 1e3, 4), "steps": 8,
                             "vertices": int(v.shape[0]), "faces": int(f.shape[0]),
-                            "binding": "p3d_mc_count -> p3d_mc_read_counts -> torch.empty x2 -> p3d_mc_emit through ctypes (capi.extract)",
+                            "binding": "p3d_mc_count -> p3d_mc_read_counts -> torch.empty x2 -> p3d_mc_emit through ctypes (capi.extract): "
+                                       "two streaming passes, no scratch (ABI v10)",
                             "timing": "back-to-back calls between two synchronisations"}
         del v, f
     except Exception as e:

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define P3D_MC_ABI_VERSION 9
+#define P3D_MC_ABI_VERSION 10
 
 /* dtype of the scalar field */
 #define P3D_F32 0
@@ -94,8 +94,8 @@ typedef struct p3d_mc_slab {
                                      4                         3
                                      5                         4 (the vertex buffer part 4 was given; none if it had none)
                                      6                         4, or a finished extraction (0, 2, 5, 6)
-                                     p3d_mc_emit               p3d_mc_count, 4, or a finished extraction
-                                (p3d_mc_count and the batched entry also start anew; the state diagram is in
+                                     p3d_mc_emit               p3d_mc_count[_scan], 4, or a finished extraction
+                                (p3d_mc_count, p3d_mc_count_scan and the batched entry also start anew; the state diagram is in
                                 INTEGRATION.md.)  The reference's boundary has no such state: marching_cubes.h:14-15. */
     int64_t vertex_id_base;      /* added to every locally owned vertex id written into faces */
     int64_t halo_vertex_id_base; /* added to the imported records of the halo plane */
@@ -121,12 +121,22 @@ typedef struct p3d_mc_slab {
  * instead of 12 B/voxel. */
 int p3d_mc_workspace_bytes(int64_t rx, int64_t ry, int64_t rz, size_t* bytes);
 
-/* Phase 1 (replaces count_vertices_faces_kernel launch, marching_cubes.cu:242-249): classify the
- * field against `thresh` (inside = value > thresh, strict), build the per-voxel sign bitfield and
- * the per-unit vertex-id records in `ws`, and count vertices and triangles.  Totals stay on the
- * device in `ws` until p3d_mc_read_counts.  `slab` may be NULL (whole grid). */
+/* Phase 1 (replaces the count_vertices_faces_kernel launch, marching_cubes.cu:242-249): ONE pass over the field that
+ * classifies it against `thresh` (inside = value > thresh, strict), leaves the per-voxel sign bitfield, the per-unit
+ * vertex-id records and the totals of the 32 output regions in `ws`, and counts vertices and triangles -- the streaming
+ * kernel of p3d_mc_extract_fused in count-only form (no vertex is made) + its face count.  Totals stay on the device in
+ * `ws` until p3d_mc_read_counts.  `slab` may be NULL (whole grid); of a slab only halo_last_plane is read.
+ * (ABI v10.  Until v9 this name ran a classification pass, three scans and left scan-numbered ids: that is
+ * p3d_mc_count_scan now.) */
 int p3d_mc_count(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz, float thresh,
                  const p3d_mc_slab* slab, void* ws, void* stream);
+
+/* The same counts with DETERMINISTIC dense vertex ids (a classification pass, per-unit counts, a prefix scan): what a
+ * caller runs when p3d_mc_read_counts reports bit 1 (a region of the one-pass kernels numbered more than 2^26 vertices),
+ * and what the parity tests use to get per-vertex edge keys out of p3d_mc_emit.  About 3x the time of p3d_mc_count.
+ * p3d_mc_emit behind it writes the vertices by id (gather emitter). */
+int p3d_mc_count_scan(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz, float thresh,
+                      const p3d_mc_slab* slab, void* ws, void* stream);
 
 /* Read of the totals (replaces the two .item() calls, marching_cubes.cu:251-252) of the last p3d_mc_count /
  * p3d_mc_extract_fused on this workspace.  It does NOT synchronise the stream: the kernels store the totals into
@@ -139,17 +149,27 @@ int p3d_mc_count(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz
  *          p3d_mc_emit must be used to rewrite it (ids and counts stay valid);
  *   bit 1  one of the 32 regions received more than 2^26 vertices: the ids handed out by the one-pass call are
  *          ambiguous (they are region * 2^26 + slot).  The COUNTS are still right; the caller must renumber with
- *          p3d_mc_count (dense ids by prefix scan) and then call p3d_mc_emit. */
+ *          p3d_mc_count_scan (dense ids by prefix scan) and then call p3d_mc_emit. */
 int p3d_mc_read_counts(const void* ws, int64_t* num_vertices, int64_t* num_faces, int32_t* scratch_overflow,
                        void* stream);
 
 /* Phase 2 (replaces gen_vertices_kernel, gen_faces_kernel and the epilogue, marching_cubes.cu:266-298):
  * write vertices [V,3] f32 already mapped to the bounding box (v * scale + lower, scale as in
- * :293-297 including the upper[2]-lower[1] term of :295) and faces [F,3] i32.  Must follow a
- * p3d_mc_count on the same grid/ws.  cap_vertices/cap_faces are the capacities of the two buffers
+ * :293-297 including the upper[2]-lower[1] term of :295) and faces [F,3] i32.  Must follow finished counts on the same
+ * grid / ws / stream (p3d_mc_count, p3d_mc_count_scan, part 4, or a whole p3d_mc_extract_fused).  cap_vertices / cap_faces
+ * are the capacities of the two buffers
  * in elements (rows); nothing is written past them, and a capacity that is too small is not an error
- * here (the caller compares the counts it read with the capacities it gave).  vertex_keys (nullable) receives per-vertex edge keys
- * voxel_linear*3+axis (int64, debug/parity output, local slab indexing). */
+ * here (the caller compares the counts it read with the capacities it gave).
+ * How: for a whole grid (slab = NULL) whose vertices AND faces are asked for, behind counts of the one-pass kernels, a
+ * SECOND streaming pass over the field (as the reference reads it a second time in gen_vertices_kernel): the 32 region
+ * totals of the counting pass depend on the launch geometry alone, so every region is written at its final rows of the
+ * caller's buffer -- no scratch, no copy; vertex ids are handed out anew and the faces use them.  In every other case ids
+ * handed out earlier must survive (a slab whose first plane's records are with the neighbour already; vertices or faces
+ * alone; after p3d_mc_count_scan; with vertex_keys) and a gather emitter writes the vertices by id.
+ * vertex_keys (nullable) receives per-vertex edge keys voxel_linear*3+axis (int64, debug/parity output, local slab
+ * indexing).
+ * The same-stream rule of the order check applies: p3d_mc_emit must be given the stream of the call that made the counts
+ * (the workspace is read in stream order; a host-side p3d_mc_read_counts in between does not replace that). */
 int p3d_mc_emit(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz, float thresh,
                 const float lower[3], const float upper[3], const int64_t full_res[3],
                 const p3d_mc_slab* slab, void* ws, float* vertices, int64_t cap_vertices,
@@ -256,7 +276,7 @@ int p3d_mc_shutdown(void);
  * to see which path a call took -- nothing in the data path depends on them):
  *   out[0] streaming launches                            out[1] always 0 (was: launches with the round-4 plane hand-out)
  *   out[2] streaming passes of p3d_mc_extract_fused[_batched] that wrote or counted a whole grid / stack (part 0 or 2, 3)
- *   out[3] calls of the counting / gather pair p3d_mc_count + p3d_mc_emit
+ *   out[3] calls of p3d_mc_count / p3d_mc_count_scan
  *   out[4] emissions that had no streaming pass of their own (p3d_mc_slab.part = 6)
  *   out[5] (device, stream) pairs the library currently keeps a cursor ring for (p3d_mc_release_stream / p3d_mc_shutdown)
  * Writes min(n, 6) values, returns how many. */

@@ -12,7 +12,7 @@ P3D_OK = 0
 P3D_ERANGE = -2
 
 # every symbol include/p3d_mc.h declares
-SYMBOLS = ("p3d_mc_abi_version", "p3d_last_error", "p3d_mc_workspace_bytes", "p3d_mc_count",
+SYMBOLS = ("p3d_mc_abi_version", "p3d_last_error", "p3d_mc_workspace_bytes", "p3d_mc_count", "p3d_mc_count_scan",
            "p3d_mc_read_counts", "p3d_mc_emit", "p3d_mc_plane_records", "p3d_mc_export_plane_records", "p3d_mc_profile_enable",
            "p3d_mc_profile_read", "p3d_mc_profile_stage_name", "p3d_mc_extract_fused", "p3d_mc_debug_layout",
            "p3d_mc_workspace_bytes_batched", "p3d_mc_extract_fused_batched", "p3d_mc_reload_tuning",
@@ -46,6 +46,7 @@ def lib():
         L.p3d_last_error.restype = c_char_p
         L.p3d_mc_workspace_bytes.argtypes = [c_int64, c_int64, c_int64, POINTER(c_size_t)]
         L.p3d_mc_count.argtypes = [c_void_p, c_int, c_int64, c_int64, c_int64, c_float, POINTER(Slab), c_void_p, c_void_p]
+        L.p3d_mc_count_scan.argtypes = L.p3d_mc_count.argtypes
         L.p3d_mc_read_counts.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32), c_void_p]
         L.p3d_mc_emit.argtypes = [c_void_p, c_int, c_int64, c_int64, c_int64, c_float, POINTER(c_float * 3),
                                   POINTER(c_float * 3), POINTER(c_int64 * 3), POINTER(Slab), c_void_p, c_void_p,
@@ -109,14 +110,16 @@ def _on_device_of(t):
     return torch.cuda.device(t.device)
 
 
-def count(grid, thresh, ws, slab=None):
-    """p3d_mc_count on a contiguous device tensor [rx,ry,rz]."""
+def count(grid, thresh, ws, slab=None, scan=False):
+    """p3d_mc_count on a contiguous device tensor [rx,ry,rz] (one pass, the one-pass kernels in count-only form);
+    scan=True: p3d_mc_count_scan (deterministic dense ids by prefix scan: the renumbering fallback and the parity tests'
+    keyed path)."""
     assert grid.is_cuda and grid.is_contiguous() and grid.dim() == 3
     rx, ry, rz = grid.shape
+    fn, what = (lib().p3d_mc_count_scan, "p3d_mc_count_scan") if scan else (lib().p3d_mc_count, "p3d_mc_count")
     with _on_device_of(grid):
-        _check(lib().p3d_mc_count(c_void_p(grid.data_ptr()), _dtype_code(grid), rx, ry, rz, c_float(thresh),
-                                  byref(slab) if slab is not None else None, c_void_p(ws.data_ptr()),
-                                  _stream_ptr(grid)), "p3d_mc_count")
+        _check(fn(c_void_p(grid.data_ptr()), _dtype_code(grid), rx, ry, rz, c_float(thresh),
+                  byref(slab) if slab is not None else None, c_void_p(ws.data_ptr()), _stream_ptr(grid)), what)
 
 
 def read_counts(ws, with_flags=False):
@@ -333,8 +336,8 @@ def extract_fused(grid, thresh, lower=None, upper=None, cap_vertices=None, cap_f
     extract_fused_raw(grid, thresh, lower, upper, ws, verts, faces)
     nv, nf, over = read_counts(ws, with_flags=True)
     if nv > capv or nf > capf or over:
-        if over & 2:  # ambiguous one-pass ids: dense ids by the counting call
-            count(grid, thresh, ws)
+        if over & 2:  # ambiguous one-pass ids: dense ids by the scan-numbered counting call
+            count(grid, thresh, ws, scan=True)
             nv, nf = read_counts(ws)
         verts = torch.empty((nv, 3), dtype=torch.float32, device=grid.device)
         faces = torch.empty((nf, 3), dtype=torch.int32, device=grid.device)
@@ -359,17 +362,23 @@ def export_plane_records(ws, rx, ry, rz, plane, out):
     return out
 
 
-def extract(grid, thresh, lower=None, upper=None, with_keys=False):
-    """Whole two-phase call through the C ABI on a device tensor; returns (vertices, faces[, keys])."""
+def extract(grid, thresh, lower=None, upper=None, with_keys=False, return_ws=False):
+    """Whole two-phase call through the C ABI on a device tensor -- p3d_mc_count -> p3d_mc_read_counts -> exactly sized
+    tensors -> p3d_mc_emit, the literal binding of INTEGRATION.md; returns (vertices, faces[, keys][, ws]).  with_keys:
+    the scan-numbered pair (p3d_mc_count_scan + the gather emitter), which can write a vertex's edge key next to it."""
     import torch
     rx, ry, rz = grid.shape
     lower = [0.0, 0.0, 0.0] if lower is None else lower
     upper = [rx, ry, rz] if upper is None else upper
     ws = torch.empty(workspace_bytes(rx, ry, rz), dtype=torch.uint8, device=grid.device)
-    count(grid, thresh, ws)
-    nv, nf = read_counts(ws)
+    count(grid, thresh, ws, scan=with_keys)
+    nv, nf, over = read_counts(ws, with_flags=True)
+    if over & 2 and not with_keys:   # a region numbered more than 2^26 vertices: renumber (include/p3d_mc.h)
+        count(grid, thresh, ws, scan=True)
+        nv, nf = read_counts(ws)
     verts = torch.empty((nv, 3), dtype=torch.float32, device=grid.device)
     faces = torch.empty((nf, 3), dtype=torch.int32, device=grid.device)
     keys = torch.empty((nv,), dtype=torch.int64, device=grid.device) if with_keys else None
     emit(grid, thresh, lower, upper, ws, verts, faces, keys)
-    return (verts, faces, keys) if with_keys else (verts, faces)
+    out = (verts, faces, keys) if with_keys else (verts, faces)
+    return out + (ws,) if return_ws else out

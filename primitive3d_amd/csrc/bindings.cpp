@@ -229,9 +229,9 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
         ok = !id_overflow && run_pass(ev, ef, std::max(8, 2 * slack_q), 4, false);
         if (!ok) {
             // a region numbered more than 2^26 vertices: the one-pass ids are ambiguous -> dense ids by the
-            // counting call (include/p3d_mc.h: p3d_mc_read_counts, bit 1)
+            // scan-numbered counting call (include/p3d_mc.h: p3d_mc_read_counts, bit 1; p3d_mc_count_scan)
             if (id_overflow) {
-                check_rc(p3d_mc_count(grid, P3D_F32, rx, ry, rz, thresh, nullptr, ws.data_ptr(), stream), "p3d_mc_count");
+                check_rc(p3d_mc_count_scan(grid, P3D_F32, rx, ry, rz, thresh, nullptr, ws.data_ptr(), stream), "p3d_mc_count_scan");
                 check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, nullptr, stream), "p3d_mc_read_counts");
             }
             // pathological region imbalance: the gather emitter writes by vertex id and cannot overflow

@@ -1872,7 +1872,7 @@ template <typename T, int NC, int RY>
 void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xform& t, int64_t x_origin, u64* bits,
                   uint2* rec, u64* cursors, u64* zero_next, float* scratch, u32 region_rows, u32 store_rows, int x_lo,
                   int x_hi,
-                  hipEvent_t ev0, hipEvent_t ev1, hipStream_t st, int cz_base = 0, int cz_count = -1) {
+                  hipEvent_t ev0, hipEvent_t ev1, hipStream_t st, const u64* region_first_row, int cz_base = 0, int cz_count = -1) {
     FusedGeom g;
     g.x_lo = x_lo;
     g.x_hi = x_hi;
@@ -1939,17 +1939,17 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
     if (ev0 || ev1)   // (rows split over two launches: the first carries the start event, the second the stop event)
         hipExtLaunchKernelGGL((k_fused<T, NC, RY>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, ev0, ev1, 0, grid, thresh,
                               thresh16, d, g, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                              store_rows);
+                              store_rows, region_first_row);
     else
         hipLaunchKernelGGL((k_fused<T, NC, RY>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, grid, thresh, thresh16, d, g,
-                           halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows, store_rows);
+                           halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows, store_rows, region_first_row);
 }
 
 template <typename T>
 void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xform& t, int64_t x_origin, u64* bits,
                     uint2* rec, u64* cursors, u64* zero_next, float* scratch, u32 region_rows, u32 store_rows, int x_lo,
                   int x_hi,
-                    hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
+                    hipEvent_t ev0, hipEvent_t ev1, hipStream_t st, const u64* region_first_row = nullptr) {
     // tile geometries (32 unit words per wave-plane unless noted): long rows (8 chunks x 3 rows per wave), rows of 3-4
     // chunks (rz <= 256: 4 chunks x 6 rows -- the 8-chunk tile would be half empty -- or, for a single small grid,
     // 16-unit tiles of 4 chunks x 3 rows), short rows (2 chunks x 15 rows).
@@ -1960,14 +1960,14 @@ void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const 
         // full (513 x 511 x 517: 169 -> 155 us; with 3..4 chunks left over the split measured no gain)
         const int full = (int)d.ncz - rem;
         launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                     store_rows, x_lo, x_hi, ev0, nullptr, st, 0, full);
+                                     store_rows, x_lo, x_hi, ev0, nullptr, st, region_first_row, 0, full);
         launch_fused<T, 2, 15>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                      store_rows, x_lo, x_hi, nullptr, ev1, st, full, rem);
+                                      store_rows, x_lo, x_hi, nullptr, ev1, st, region_first_row, full, rem);
         return;
     }
     if (d.ncz >= 5)
         launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                    store_rows, x_lo, x_hi, ev0, ev1, st);
+                                    store_rows, x_lo, x_hi, ev0, ev1, st, region_first_row);
     else if (d.ncz >= 3 &&
              // (only when 8-plane slabs of the wider-in-y tile still give the chip enough blocks: a single small grid is
              //  better off with more, half-empty tiles than with 2-plane slabs)
@@ -1976,18 +1976,18 @@ void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const 
         //  Perlin stacks -- a full batch of 64 and a nearly empty one --, one of 24 units ~64: 32 x 256^3 fp16 342 -> 328 us,
         //  fp32 556 -> 535 us)
         launch_fused<T, 4, 6>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                    store_rows, x_lo, x_hi, ev0, ev1, st);
+                                    store_rows, x_lo, x_hi, ev0, ev1, st, region_first_row);
     else if (d.ncz >= 3 && tuning().small16)
         // a single small grid: 16-unit tiles (4 chunks x 3 rows + halo row) -- twice the waves of the 8-chunk tile, none
         // of them half empty
         launch_fused<T, 4, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                     store_rows, x_lo, x_hi, ev0, ev1, st);
+                                     store_rows, x_lo, x_hi, ev0, ev1, st, region_first_row);
     else if (d.ncz >= 3)
         launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                    store_rows, x_lo, x_hi, ev0, ev1, st);
+                                    store_rows, x_lo, x_hi, ev0, ev1, st, region_first_row);
     else
         launch_fused<T, 2, 15>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                      store_rows, x_lo, x_hi, ev0, ev1, st);
+                                      store_rows, x_lo, x_hi, ev0, ev1, st, region_first_row);
 }
 
 Xform make_xform(const Dims& d, const float lower[3], const float upper[3], const int64_t full_res[3]) {
@@ -2001,6 +2001,41 @@ Xform make_xform(const Dims& d, const float lower[3], const float upper[3], cons
     t.oy = lower[1];
     t.oz = lower[2];
     return t;
+}
+
+// p3d_mc_emit behind a counting pass (p3d_mc_count, or any finished one-pass extraction) of a whole grid: a SECOND streaming
+// pass.  Which wave-plane adds to which of the 32 cursors depends on the launch geometry alone, so the region totals of the
+// counting pass -- their prefix is in the workspace header -- hold for this pass as well: region r is stored at its final
+// rows of the caller's exactly sized buffer (no scratch, no copy), the records are rewritten with this pass's slots, and the
+// face launch translates them with this pass's cursors.  Replaces gen_vertices_kernel + gen_faces_kernel + the epilogue,
+// marching_cubes.cu:266-298 (the reference, too, reads the field a second time there).
+template <typename T>
+int emit_stream_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xform& t, char* ws, float* verts,
+                     int64_t capv, int32_t* faces, int64_t capf, hipStream_t st) {
+    u64* hdr = (u64*)(ws + w.hdr);
+    u64* bits = (u64*)(ws + w.bits);
+    uint2* rec = (uint2*)(ws + w.rec);
+    u32 *csum = (u32*)(ws + w.chunk_sum), *woff = (u32*)(ws + w.wave_off);
+    u32* cpre = (w.nchunks > kPreMinChunks && !tuning().no_chunk_pre) ? (u32*)(ws + w.chunk_pre) : nullptr;
+    u64 *cursors = nullptr, *zero_next = nullptr;
+    RingLease lease;   // (released when this function returns: both launches are enqueued by then)
+    if (int rc = cursor_block_for(st, &lease, &cursors, &zero_next)) return rc;
+    const bool timed = g_prof_mode != 0;
+    if (timed) g_ev_used[ST_EMIT_VERTS] = true;
+    dispatch_fused<T>(grid, d, thresh, 0, t, 0, bits, rec, cursors, zero_next, verts, 1u << 26,
+                      (u32)std::min<int64_t>(capv, 0xffffffffll), 0, (int)d.rx, timed ? g_ev[ST_EMIT_VERTS][0] : nullptr,
+                      timed ? g_ev[ST_EMIT_VERTS][1] : nullptr, st, hdr + H_PREFIX);
+    HIP_TRY(hipGetLastError());
+    lease.commit();
+    if (w.nb_f > 0 && capf > 0) {
+        StageTimer tm(ST_EMIT_FACES, st);
+        const FaceArgs a{1, 0, 0, 0, nullptr, 0, 1, w.tpp, w.xw, (int)w.cpi, csum, cpre, woff, (const u32*)(ws + w.tile_tris),
+                         cursors, nullptr, 0};
+        const CompactArgs none{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr, 1u << 26, 1, nullptr};
+        launch_faces(d, w, bits, rec, a, none, hdr, faces, capf, true, st);
+    }
+    HIP_TRY(hipGetLastError());
+    return P3D_OK;
 }
 
 template <typename T>
@@ -2198,9 +2233,10 @@ int fused_stack_impl(const T* grids, const Dims& d, const Ws& w, float thresh, c
 // with split_plane 0, p3d_mc_count, the batched entry) is always legal and resets the entry, so a workspace address that
 // an allocator hands out again never inherits a verdict; the table holds the kMaxExtractions most recently used workspaces.
 enum Phase { PH_NONE = 0, PH_INTERIOR /* after part 1 */, PH_STREAMED /* after part 3 */, PH_COUNTED /* after part 4 */,
-             PH_DONE /* after part 0, 2, 5, 6 */, PH_COUNT_CALL /* after p3d_mc_count */, PH_STACK /* the batched entry */ };
+             PH_DONE /* after part 0, 2, 5, 6 */, PH_COUNT_CALL /* after p3d_mc_count */, PH_STACK /* the batched entry */,
+             PH_COUNT_SCAN /* after p3d_mc_count_scan */ };
 const char* const k_phase_names[] = {"nothing", "part 1", "part 3", "part 4", "a finished extraction (part 0, 2, 5 or 6)",
-                                     "p3d_mc_count", "p3d_mc_extract_fused_batched"};
+                                     "p3d_mc_count", "p3d_mc_extract_fused_batched", "p3d_mc_count_scan"};
 struct Extraction {
     int phase = PH_NONE;
     hipStream_t stream = nullptr;
@@ -2220,7 +2256,7 @@ uint64_t g_proto_clock = 0;
 
 struct ProtoCall {   // what one call presents
     const void* ws;
-    int part;        // 0..6, or -1 p3d_mc_count, -2 p3d_mc_emit, -3 the batched entry
+    int part;        // 0..6, or -1 p3d_mc_count, -2 p3d_mc_emit, -3 the batched entry, -4 p3d_mc_count_scan
     hipStream_t stream;
     int64_t rx, ry, rz, split;
     int dtype;
@@ -2247,7 +2283,7 @@ int proto_check(const ProtoCall& c, Extraction* out) {
         if (it != g_proto.end()) e = it->second;
     }
     const int last = e.phase;
-    const bool start = c.part == 0 || c.part == 1 || (c.part == 3 && c.split == 0) || c.part == -1 || c.part == -3;
+    const bool start = c.part == 0 || c.part == 1 || (c.part == 3 && c.split == 0) || c.part == -1 || c.part == -3 || c.part == -4;
     if (!start) {
         // every continuation: the same stream and grid shape as the part that started the extraction
         if (last == PH_NONE || last == PH_STACK) {
@@ -2260,7 +2296,7 @@ int proto_check(const ProtoCall& c, Extraction* out) {
     }
     const bool same_scratch = c.scratch == e.scratch && c.scratch_rows == e.scratch_rows;
     switch (c.part) {
-        case 0: case 1: case -1: case -3: break;
+        case 0: case 1: case -1: case -3: case -4: break;
         case 2:
             if (last != PH_INTERIOR) return proto_fail("part 2 needs part 1 before it", last);
             if (c.split != e.split) return proto_fail("part 2 must continue at part 1's split_plane", last);
@@ -2289,8 +2325,8 @@ int proto_check(const ProtoCall& c, Extraction* out) {
             if (!same_scratch) return proto_fail("part 6 must be given the scratch buffer the field was streamed into", last);
             break;
         case -2:
-            if (last != PH_COUNT_CALL && last != PH_COUNTED && last != PH_DONE)
-                return proto_fail("p3d_mc_emit needs finished counts (p3d_mc_count, part 4 or a whole extraction) before it", last);
+            if (last != PH_COUNT_CALL && last != PH_COUNT_SCAN && last != PH_COUNTED && last != PH_DONE)
+                return proto_fail("p3d_mc_emit needs finished counts (p3d_mc_count, p3d_mc_count_scan, part 4 or a whole extraction) before it", last);
             break;
         default: return fail(P3D_EINVAL, "bad slab part%s");
     }
@@ -2311,6 +2347,7 @@ int proto_check(const ProtoCall& c, Extraction* out) {
             break;
         case -1: e.phase = PH_COUNT_CALL; break;
         case -3: e.phase = PH_STACK; break;
+        case -4: e.phase = PH_COUNT_SCAN; break;
         default: break;   // (p3d_mc_emit leaves the phase where it is)
     }
     *out = e;
@@ -2359,6 +2396,31 @@ int p3d_mc_count(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz
     if (dtype != P3D_F32 && dtype != P3D_F16) return fail(P3D_EINVAL, "unknown dtype%s");
     Extraction next;
     if (int rc = proto_check(ProtoCall{ws, -1, st, rx, ry, rz, 0, dtype, nullptr, 0, nullptr, 0}, &next)) return rc;
+    // the one-pass kernels in count-only form: the streaming kernel without a vertex buffer (sign words, records, the 32
+    // region totals) + the face count; the finishing block leaves V, F, the flags and the region prefixes in the header
+    p3d_mc_slab whole{};
+    if (slab) whole = *slab;
+    whole.part = 0;
+    const float unit_lo[3] = {0.f, 0.f, 0.f}, unit_hi[3] = {1.f, 1.f, 1.f};
+    const Xform t = make_xform(d, unit_lo, unit_hi, nullptr);   // (no vertex is stored: the box does not matter)
+    g_counters[3].fetch_add(1, std::memory_order_relaxed);
+    const int rc = dtype == P3D_F32
+                       ? fused_impl((const float*)grid, d, w, thresh, t, &whole, (char*)ws, nullptr, 0, nullptr, 0, nullptr, 0, st, &next.held)
+                       : fused_impl((const __half*)grid, d, w, thresh, t, &whole, (char*)ws, nullptr, 0, nullptr, 0, nullptr, 0, st, &next.held);
+    if (rc == P3D_OK) proto_commit(ws, next);
+    return rc;
+}
+
+int p3d_mc_count_scan(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz, float thresh,
+                      const p3d_mc_slab* slab, void* ws, void* stream) {
+    if (!grid || !ws) return fail(P3D_EINVAL, "null pointer%s");
+    if (int rc = check_dims(rx, ry, rz)) return rc;
+    const Dims d = make_dims(rx, ry, rz);
+    const Ws w = make_ws(d);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype != P3D_F32 && dtype != P3D_F16) return fail(P3D_EINVAL, "unknown dtype%s");
+    Extraction next;
+    if (int rc = proto_check(ProtoCall{ws, -4, st, rx, ry, rz, 0, dtype, nullptr, 0, nullptr, 0}, &next)) return rc;
     const int rc = dtype == P3D_F32 ? count_impl((const float*)grid, d, w, thresh, slab, (char*)ws, st)
                                     : count_impl((const __half*)grid, d, w, thresh, slab, (char*)ws, st);
     if (rc == P3D_OK) proto_commit(ws, next);
@@ -2399,6 +2461,15 @@ int p3d_mc_emit(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz,
     if (dtype != P3D_F32 && dtype != P3D_F16) return fail(P3D_EINVAL, "unknown dtype%s");
     Extraction next;
     if (int rc = proto_check(ProtoCall{ws, -2, st, rx, ry, rz, 0, dtype, nullptr, 0, nullptr, 0}, &next)) return rc;
+    // A whole grid whose vertices AND faces are (re)written, behind counts made by the one-pass kernels: a second streaming
+    // pass into the exactly sized buffers.  Ids handed out before must survive in every other case -- a slab (its first
+    // plane's records may already be with the neighbour), vertices or faces alone, the keys of the parity tests, ids
+    // renumbered by p3d_mc_count_scan -- and there the gather emitter writes by id.
+    if (!slab && !vertex_keys && cap_vertices > 0 && cap_faces > 0 && next.phase != PH_COUNT_SCAN) {
+        if (dtype == P3D_F32)
+            return emit_stream_impl((const float*)grid, d, w, thresh, t, (char*)ws, vertices, cap_vertices, faces, cap_faces, st);
+        return emit_stream_impl((const __half*)grid, d, w, thresh, t, (char*)ws, vertices, cap_vertices, faces, cap_faces, st);
+    }
     if (dtype == P3D_F32)
         return emit_impl((const float*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices, faces,
                          cap_faces, vertex_keys, st);

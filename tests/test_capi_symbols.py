@@ -56,7 +56,7 @@ def test_raycaster_header_functions_are_exported(built):
 
 def test_host_only_entry_points(built):
     from primitive3d_amd import capi
-    assert capi.lib().p3d_mc_abi_version() == 9
+    assert capi.lib().p3d_mc_abi_version() == 10
     n512 = capi.workspace_bytes(512, 512, 512)
     assert 0.25 * 512 ** 3 < n512 < 0.40 * 512 ** 3  # bits + records + counts: ~0.3 B/voxel (reference: 12 B/voxel)
     lay = capi.debug_layout(10, 9, 66)

@@ -56,6 +56,63 @@ def test_small_cases_match_oracle(gpu, name):
         assert hip[1].min() >= 0 and hip[1].max() < hip[0].shape[0]
 
 
+def _hip_extract_pair(gpu, g, thresh, lower, upper, dtype=torch.float32):
+    """The literal two-phase binding: p3d_mc_count -> read (V, F) -> exactly sized tensors -> p3d_mc_emit,
+    i.e. the one-pass kernels in count-only form and a second streaming pass that stores every region at its final rows;
+    vertex keys rebuilt on the host from the workspace (tests/ws_keys.py)."""
+    from primitive3d_amd import capi
+    from tests.ws_keys import vertex_keys_from_workspace
+    t = torch.from_numpy(np.ascontiguousarray(g)).to(gpu).to(dtype)
+    v, f, ws = capi.extract(t, thresh, lower, upper, return_ws=True)
+    torch.cuda.synchronize()
+    keys = vertex_keys_from_workspace(ws.cpu().numpy(), t.shape, v.shape[0], capi.debug_layout(*t.shape))
+    return v.cpu().numpy(), f.cpu().numpy(), keys
+
+
+@pytest.mark.parametrize("name", sorted(small_cases().keys()))
+def test_small_cases_count_emit_pair_match_oracle(gpu, name):
+    g, thresh, lower, upper = small_cases()[name]
+    _assert_same_mesh(_hip_extract_pair(gpu, g, thresh, lower, upper), oracle_extract(g, thresh, lower, upper))
+
+
+@pytest.mark.parametrize("shape,dtype", [((40, 50, 517), torch.float32), ((33, 30, 1100), torch.float32),
+                                         ((70, 200, 256), torch.float16), ((9, 100, 129), torch.float32),
+                                         ((130, 131, 200), torch.float32), ((24, 40, 512), torch.float32)])
+def test_count_emit_pair_on_the_tile_geometries(gpu, shape, dtype):
+    """Every tile geometry of the streaming kernel (8 x 3, 4 x 6 / 4 x 3, 2 x 15, rows split over two launches, two z tiles,
+    enough blocks for the fixed cursor groups and few enough for the rotating ones): the second pass must reproduce the
+    first pass's 32 region totals exactly, or vertices land in a neighbour's rows -- the whole mesh against the oracle,
+    on Perlin noise and (last shape) on white noise."""
+    from primitive3d_amd.fields import perlin_grid
+    if shape == (24, 40, 512):
+        g = np.random.default_rng(3).standard_normal(shape).astype(np.float32)
+    else:
+        g = perlin_grid(shape, period=14, seed=sum(shape)).numpy()
+    if dtype == torch.float16:
+        g = g.astype(np.float16)
+    ref = oracle_extract(g.astype(np.float32), 0.03)
+    _assert_same_mesh(_hip_extract_pair(gpu, g, 0.03, None, None, dtype=dtype), ref)
+
+
+def test_count_emit_pair_tolerates_a_too_small_vertex_buffer(gpu):
+    """p3d_mc_emit writes nothing past the capacities it is given (include/p3d_mc.h): a vertex buffer shorter than V gets
+    the rows that fit -- regions are clipped at the end of the buffer, the guard rows behind it stay untouched."""
+    from primitive3d_amd import capi
+    g, thresh, lower, upper = small_cases()["noise_33x17x200"]
+    t = torch.from_numpy(g).to(gpu)
+    lower = [0.0] * 3 if lower is None else lower
+    upper = [float(n) for n in t.shape] if upper is None else upper
+    ws = torch.empty(capi.workspace_bytes(*t.shape), dtype=torch.uint8, device=gpu)
+    capi.count(t, thresh, ws)
+    nv, nf = capi.read_counts(ws)
+    short = nv // 2
+    v = torch.full((short + 64, 3), -7.0, device=gpu)
+    f = torch.full((nf, 3), -1, dtype=torch.int32, device=gpu)
+    capi.emit(t, thresh, lower, upper, ws, v[:short], f)
+    torch.cuda.synchronize()
+    assert (v[short:] == -7.0).all() and int(f.min()) >= 0 and int(f.max()) < nv
+
+
 @pytest.mark.parametrize("name", sorted(small_cases().keys()))
 def test_small_cases_fused_match_oracle(gpu, name):
     g, thresh, lower, upper = small_cases()[name]
