@@ -94,6 +94,24 @@ def test_count_emit_pair_on_the_tile_geometries(gpu, shape, dtype):
     _assert_same_mesh(_hip_extract_pair(gpu, g, 0.03, None, None, dtype=dtype), ref)
 
 
+@pytest.mark.parametrize("name", ["noise_33x17x200", "perlin48", "noise_9x5x129"])
+def test_counting_pass_alone_leaves_consistent_records(gpu, name):
+    """p3d_mc_count makes no vertex, but its records are what a slab's gather emitter and the record export read: every id
+    in [0, V) must be assigned to exactly one crossing edge (tests/ws_keys.py checks that while it rebuilds the keys), and
+    the keys must be the oracle's."""
+    from primitive3d_amd import capi
+    from tests.ws_keys import vertex_keys_from_workspace
+    g, thresh, lower, upper = small_cases()[name]
+    t = torch.from_numpy(np.ascontiguousarray(g)).to(gpu)
+    ws = torch.empty(capi.workspace_bytes(*t.shape), dtype=torch.uint8, device=gpu)
+    capi.count(t, thresh, ws)
+    nv, nf = capi.read_counts(ws)
+    torch.cuda.synchronize()
+    keys = vertex_keys_from_workspace(ws.cpu().numpy(), t.shape, nv, capi.debug_layout(*t.shape))
+    rk = oracle_extract(g, thresh, lower, upper)[2]
+    assert (nv, nf) == oracle_count(g, thresh) and np.array_equal(np.sort(keys), np.sort(rk))
+
+
 def test_count_emit_pair_tolerates_a_too_small_vertex_buffer(gpu):
     """p3d_mc_emit writes nothing past the capacities it is given (include/p3d_mc.h): a vertex buffer shorter than V gets
     the rows that fit -- regions are clipped at the end of the buffer, the guard rows behind it stay untouched."""
