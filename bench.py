@@ -147,6 +147,21 @@ def other_configs(p3d, capi, perlin_grid, dev):
     measure("c2", "256x256x256 fp32 bunny SDF (examples/data/bunny.npy trilinearly resampled from 66^3), iso 0",
             lambda: p3d.libPrim3D.marching_cubes(g2, 0.0, [0.0] * 3, [256.0] * 3), 256 ** 3, 4, steps=40, warmup=5)
     del g2
+    # the reference's OWN example inputs at their own sizes: examples/sphere.py:8-9 verbatim (200^3,
+    # V = 11766 / F = 23528: marching_cubes.cu on this field) and examples/data/bunny.npy as it is
+    # (66^3, 13282 / 26560).  Tiny: a call is launch latency and ramp, not bandwidth
+    from primitive3d_amd.fields import sphere_grid
+    gs = torch.tensor(sphere_grid(200)).to(dev).to(torch.float32).contiguous()
+    measure("sphere200", "200x200x200 sphere field of examples/sphere.py:8-9 (centre 50, radius 25; int64 in the example, float32 "
+                         "on the device as its wrapper makes it, marching_cubes.py:87), iso 0",
+            lambda: p3d.libPrim3D.marching_cubes(gs, 0.0, [0.0] * 3, [200.0] * 3), 200 ** 3, 4, steps=40, warmup=5)
+    assert (out["sphere200"]["vertices"], out["sphere200"]["faces"]) == (11766, 23528), out["sphere200"]
+    del gs
+    gb = b66.to(dev).to(torch.float32).contiguous()
+    measure("bunny66", "66x66x66 fp32 bunny SDF (examples/data/bunny.npy as shipped, examples/bunny_sdf.py), iso 0",
+            lambda: p3d.libPrim3D.marching_cubes(gb, 0.0, [0.0] * 3, [66.0] * 3), 66 ** 3, 4, steps=40, warmup=5)
+    assert (out["bunny66"]["vertices"], out["bunny66"]["faces"]) == (13282, 26560), out["bunny66"]
+    del gb
     g5 = torch.stack([perlin_grid((256,) * 3, period=64, seed=s, device=dev).half() for s in range(32)])
     measure("c5", "batch of 32 x 256x256x256 fp16 Perlin SDF grids (period 64, seeds 0..31), iso 0, one "
                   "marching_cubes_batched call per step",

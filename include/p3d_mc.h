@@ -113,6 +113,12 @@ typedef struct p3d_mc_slab {
     void* export_first_plane_to; /* part 3 only, optional DEVICE buffer of bytes_per_plane bytes (p3d_mc_plane_records): the
                                     dense vertex-id records of local plane 0 are written there by the launch that writes
                                     the header -- what p3d_mc_export_plane_records does as a launch of its own */
+    int32_t defer_totals;        /* parts 4 and 5 (ABI v10): 1 = part 4 does not report V and F to the host (no totals launch
+                                    behind the face count); the part 5 that follows -- it must be given the same 1 -- reports
+                                    them from the first block of its face launch.  For a caller that enqueues part 5 with a
+                                    capacity guess before it has seen the totals (SlabExtractor's device path): one launch
+                                    less on the stream per extraction */
+    int32_t reserved;            /* 0 */
 } p3d_mc_slab;
 
 /* Bytes of device scratch p3d_mc_count / p3d_mc_emit need for an [rx,ry,rz] grid.

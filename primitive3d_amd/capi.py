@@ -24,7 +24,7 @@ class Slab(ctypes.Structure):
     _fields_ = [("halo_last_plane", c_int32), ("part", c_int32), ("vertex_id_base", c_int64),
                 ("halo_vertex_id_base", c_int64), ("x_origin", c_int64), ("split_plane", c_int64),
                 ("rank_counts", c_void_p), ("rank", c_int32), ("rank_counts_stride", c_int32),
-                ("export_first_plane_to", c_void_p)]
+                ("export_first_plane_to", c_void_p), ("defer_totals", c_int32), ("reserved", c_int32)]
 
 
 class P3DError(RuntimeError):

@@ -2129,7 +2129,9 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     // those first blocks only.
     const bool faces_here = w.nb_f > 0 && capf > 0 && (!halo || part >= 5);
     u64 seq = 0;
-    u64* mb = part >= 5 ? nullptr : mailbox_open(ws, &seq);
+    // (p3d_mc_slab.defer_totals: part 4 reports nothing, the part 5 behind it reports V and F from its first block)
+    const bool defer = slab && slab->defer_totals != 0 && (part == 4 || part == 5);
+    u64* mb = (part >= 5 && !(defer && part == 5)) || (defer && part == 4) ? nullptr : mailbox_open(ws, &seq);
     // the copy of the vertex regions is split over the two launches: `early` of `nparts` slices of every region ride
     // with the counting kernel (VALU-bound, HBM idle), the rest with k_faces
     const bool copy = scratch && capv > 0;
@@ -2143,8 +2145,10 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         if (cpre) hipLaunchKernelGGL(k_chunk_prefix, dim3(1), dim3(1024), 0, st, csum, (int)w.nchunks, cpre);
     }
     if (part == 4) {  // totals to the host now; the faces (and the rest of the vertex copy) follow in part 5
-        StageTimer tm(ST_SCAN_F, st);
-        hipLaunchKernelGGL(k_face_total, dim3(1), dim3(kBlock), 0, st, csum, (int)w.nchunks, hdr, mb, seq, 1);
+        if (!defer) {
+            StageTimer tm(ST_SCAN_F, st);
+            hipLaunchKernelGGL(k_face_total, dim3(1), dim3(kBlock), 0, st, csum, (int)w.nchunks, hdr, mb, seq, 1);
+        }
         HIP_TRY(hipGetLastError());
         return P3D_OK;
     }
@@ -2154,7 +2158,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
                          (slab && slab->rank_counts_stride > 0) ? slab->rank_counts_stride : 1, w.tpp, w.xw, (int)w.cpi,
                      csum, cpre, woff, (const u32*)(ws + w.tile_tris), cursors, mb, seq};
     const CompactArgs cp{copy ? scratch : nullptr, verts, capv, store_rows, region_rows, (nparts - early) * kRegions, early,
-                         nparts, part >= 5 ? 0 : 1, csum, (int)w.nchunks, cursors, id_limit, 1, nullptr};
+                         nparts, (part >= 5 && !(defer && part == 5)) ? 0 : 1, csum, (int)w.nchunks, cursors, id_limit, 1, nullptr};
     StageTimer tm(ST_EMIT_FACES, st);
     launch_faces(d, w, bits, rec, a, cp, hdr, faces, capf, faces_here, st);
     HIP_TRY(hipGetLastError());

@@ -97,9 +97,14 @@ class HipBackend:
         the all-gather, so that every rank learns every rank's vertex count AND overflow flags."""
         return self._ws[:24].view(torch.int64)
 
-    def launch_finalize(self):
-        """Part 4: face count + the first slices of the vertex compaction; V and F go to the host mailbox."""
-        self._call.fused(self._mk(4, getattr(self, "_split", 0)), self._verts, self._scratch, None)
+    def launch_finalize(self, defer_totals=False):
+        """Part 4: face count + the first slices of the vertex compaction; V and F go to the host mailbox -- unless
+        `defer_totals`: then the part 5 that finish_on_device enqueues right behind reports them from the first block of
+        its face launch (p3d_mc_slab.defer_totals: no totals launch on the stream)."""
+        slab = self._mk(4, getattr(self, "_split", 0))
+        self._deferred = bool(defer_totals) and getattr(self, "_capf", None) is not None
+        slab.defer_totals = 1 if self._deferred else 0
+        self._call.fused(slab, self._verts, self._scratch, None)
         self._split = 0
         self._slab = self._mk()
 
@@ -146,7 +151,9 @@ class HipBackend:
             faces = self._emit_faces((0, 0, rank_counts, rank))
         else:
             faces = torch.empty((capf, 3), dtype=torch.int32, device=self.device)
-            self._call.fused(self._mk(5, 0, 0, 0, rank_counts, rank), self._verts, self._scratch, faces)
+            slab5 = self._mk(5, 0, 0, 0, rank_counts, rank)
+            slab5.defer_totals = 1 if getattr(self, "_deferred", False) else 0
+            self._call.fused(slab5, self._verts, self._scratch, faces)
             nv, nf, verts, overflow = self._read_totals()
             self._scratch = None
             self._copy_pending = False
@@ -405,7 +412,7 @@ class SlabExtractor:
                 counts_ready.record()
             self._mark("all-gather of vertex counts")
             rec_works = shift_to_prev(send_buf, self.records_recv_buffer())
-            be.launch_finalize()
+            be.launch_finalize(defer_totals=True)   # (from the second call on: the faces follow with a capacity guess)
             self._mark("face count + early vertex copy")
             for w in rec_works:
                 w.wait()

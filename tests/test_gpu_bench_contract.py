@@ -50,8 +50,11 @@ def test_default_run_reports_the_other_configs(gpu):
     r = d["roofline"]
     assert r["traffic"] > r["alg_bytes_per_launch"] and r["frac"] <= r["traffic_frac"] < 1.0
     oc = d["other_configs"]
-    assert sorted(oc) == ["c2", "c3_4oct", "c4_1gpu", "c4_rank_slab", "c5", "sphere512"]
-    nvox = {"c2": 256 ** 3, "c5": 32 * 256 ** 3, "c4_1gpu": 1024 ** 3, "c3_4oct": 512 ** 3, "sphere512": 512 ** 3,
+    assert sorted(oc) == ["bunny66", "c2", "c3_4oct", "c4_1gpu", "c4_rank_slab", "c5", "sphere200", "sphere512"]
+    # the reference's own example inputs at their own sizes, with the counts its CUDA kernels give
+    assert (oc["sphere200"]["vertices"], oc["sphere200"]["faces"]) == (11766, 23528)
+    assert (oc["bunny66"]["vertices"], oc["bunny66"]["faces"]) == (13282, 26560)
+    nvox = {"sphere200": 200 ** 3, "bunny66": 66 ** 3, "c2": 256 ** 3, "c5": 32 * 256 ** 3, "c4_1gpu": 1024 ** 3, "c3_4oct": 512 ** 3, "sphere512": 512 ** 3,
             "c4_rank_slab": 128 * 1024 ** 2}
     for k, c in oc.items():
         assert "error" not in c, (k, c)
