@@ -87,8 +87,10 @@ typedef struct p3d_mc_slab {
                                 P3D_EINVAL with a message for every successor this table does not have:
                                      call                      legal after (on the same workspace)
                                      0, 1, 3 with split 0      anything (starts a new extraction; each takes the next of the
-                                                               stream's 16 pre-cleared cursor blocks -- part 1 keeps its
-                                                               block for parts 2 / 3 while up to 13 others start)
+                                                               stream's 16 pre-cleared cursor blocks -- part 1 HOLDS its
+                                                               block for parts 2 / 3: other starts step over it, however
+                                                               many; with 15 blocks held a start keeps its cursors in its
+                                                               workspace header instead)
                                      2                         1 (same split_plane)
                                      3 with split_plane > 0    1 (same split_plane)
                                      4                         3
@@ -285,7 +287,8 @@ int p3d_mc_shutdown(void);
  *   out[3] calls of p3d_mc_count / p3d_mc_count_scan
  *   out[4] emissions that had no streaming pass of their own (p3d_mc_slab.part = 6)
  *   out[5] (device, stream) pairs the library currently keeps a cursor ring for (p3d_mc_release_stream / p3d_mc_shutdown)
- * Writes min(n, 6) values, returns how many. */
+ *   out[6] bytes of device memory those rings hold (it returns to 0 when every ring has been freed)
+ * Writes min(n, 7) values, returns how many. */
 int p3d_mc_debug_counters(int64_t* out, int n);
 
 const char* p3d_last_error(void);

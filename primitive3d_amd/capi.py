@@ -160,11 +160,11 @@ def shutdown():
 
 def debug_counters():
     """p3d_mc_debug_counters: what the library has launched since it was loaded."""
-    out = (c_int64 * 6)()
-    n = lib().p3d_mc_debug_counters(out, 6)
-    assert n == 6, n
+    out = (c_int64 * 7)()
+    n = lib().p3d_mc_debug_counters(out, 7)
+    assert n == 7, n
     return {"streaming_launches": out[0], "streaming_passes": out[2], "count_emit_calls": out[3],
-            "emissions_without_a_pass": out[4], "stream_rings": out[5]}
+            "emissions_without_a_pass": out[4], "stream_rings": out[5], "ring_bytes": out[6]}
 
 
 def reload_tuning():

@@ -39,7 +39,8 @@ struct CapHint {
     int64_t nv[kHintCalls] = {0, 0, 0, 0}, nf[kHintCalls] = {0, 0, 0, 0};
     int n = 0;        // calls recorded (the ring's next slot is n % kHintCalls)
     int64_t peak_v = 0;   // the most vertices any call on this shape produced: bounds the vertex SCRATCH (below)
-    int slack_q = 5;  // headroom of every scratch region in quarters (5 = 1.25x); grows after a region overflow
+    int slack_q = 5;  // headroom of every scratch region in quarters (5 = 1.25x); doubles after a region overflow ...
+    int clean_calls = 0;   // ... and halves again after kSlackDecayCalls calls in a row without one (it used to stay for good)
     uint64_t last_use = 0;
     int64_t max_v() const { return *std::max_element(nv, nv + kHintCalls); }
     int64_t max_f() const { return *std::max_element(nf, nf + kHintCalls); }
@@ -207,7 +208,14 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
         }
         CapHint& h = g_cap_hint[key];
         h.record(nv, nf);
-        h.slack_q = region_overflow ? std::min(2 * slack_q, 32) : slack_q;
+        constexpr int kSlackDecayCalls = 64;
+        if (region_overflow) {
+            h.slack_q = std::min(2 * slack_q, 32);
+            h.clean_calls = 0;
+        } else if (++h.clean_calls >= kSlackDecayCalls && h.slack_q > 5) {
+            h.slack_q = std::max(5, h.slack_q / 2);
+            h.clean_calls = 0;
+        }
         h.last_use = ++g_cap_clock;
     }
     if (exact_done) return {vertices, faces};

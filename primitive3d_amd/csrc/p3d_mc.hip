@@ -1551,6 +1551,7 @@ std::atomic<int> g_fail_after_lease{0};
 // what has been launched so far (p3d_mc_debug_counters): fixed-slab / dynamic streaming launches, streaming passes, count+emit calls,
 // emissions without a streaming pass of their own (part 6)
 std::atomic<int64_t> g_counters[5];
+std::atomic<int64_t> g_ring_bytes{0};   // device memory the cursor rings hold right now (p3d_mc_debug_counters, out[6])
 void apply_tuning(const Tuning& t) {
     g_tuning = t;
 #if P3D_DEV_HOOKS
@@ -1564,18 +1565,21 @@ const Tuning& tuning() {
 
 // ---- cursor blocks ---------------------------------------------------------------------------------
 // The streaming kernel's 32 output cursors must be zero when a call starts.
-// Instead of a fill kernel per call the library owns, per (device, stream), a ring of kCursorRing cleared blocks:
-// call n uses block n % kCursorRing and its streaming kernel clears block (n + 1) % kCursorRing, whose last user ran
-// kCursorRing - 1 calls earlier on the same stream (stream order makes that safe).  A slab streamed in two parts
-// keeps its block for the second part.
-constexpr int kCursorRing = 16;   // (an extraction in several calls keeps its block while up to 13 others start on the stream)
+// Instead of a fill kernel per call the library owns, per (device, stream), a ring of kCursorRing blocks: a starting call
+// takes the block its predecessor's streaming kernel cleared for it (`next_slot`), and its own kernel clears the block the
+// NEXT starting call will take -- the first one behind its own that no extraction is holding (stream order makes the
+// clearing safe: that block's last user ran earlier on the same stream).  A slab streamed in two parts HOLDS its block from
+// part 1 to part 2 / 3: starting calls step over held blocks, however many of them run in between (until round 5 a held
+// block was simply overrun after 13 other starts, and the continuing part refused -- ADVICE r05).
+constexpr int kCursorRing = 16;
 constexpr int kRingSlotWords = kCursorBlockWords;   // the 32 cursors of one call
 struct CursorRing {
     int dev = -1;
     hipStream_t stream = nullptr;
     u64* base = nullptr;
-    int cur = 0;
-    uint64_t gen = 0;   // blocks handed out so far (a continuing part checks that its block has not come round again)
+    int next_slot = 0;      // the block the next starting call takes: cleared (by the memset at creation, or by the kernel of
+                            // the call that started before it)
+    unsigned held = 0;      // bit s: block s is held by an extraction between its part 1 and its part 2 / 3
     std::mutex mu;   // held by a call from the moment it takes its block until its LAST kernel is enqueued
 };
 // (device, stream) -> ring.  shared_ptr: a call's lease keeps its ring alive while p3d_mc_release_stream / p3d_mc_shutdown
@@ -1589,8 +1593,17 @@ struct HeldBlock {
     u64* cursors = nullptr;               // null: the extraction keeps its cursors in its workspace header
     std::shared_ptr<CursorRing> ring;
     u64* ring_base = nullptr;             // the ring's allocation when the block was taken (a released ring is gone)
-    uint64_t gen = 0;                     // ring->gen right after the block was taken
+    int slot = -1;                        // its index in the ring (bit of CursorRing::held)
 };
+// gives a held block back to its ring (the continuing part has been enqueued; or the extraction was abandoned: a new start
+// on its workspace, its entry leaving the protocol table)
+void release_held(HeldBlock* h) {
+    if (h->cursors && h->ring) {
+        std::lock_guard<std::mutex> g(h->ring->mu);
+        if (h->ring->base == h->ring_base && h->slot >= 0) h->ring->held &= ~(1u << h->slot);
+    }
+    *h = HeldBlock();
+}
 
 // A call's hold on its stream's ring.  Two host threads may share one stream (through ctypes the GIL is released): the
 // block a call uses is cleared by the streaming kernel of the call BEFORE it in ring order, and is read by all three of
@@ -1600,21 +1613,22 @@ struct HeldBlock {
 struct RingLease {
     std::shared_ptr<CursorRing> ring;
     std::unique_lock<std::mutex> lock;
-    int next = 0;
+    int take = 0, clears = 0;
     // The ring moves on only when the call's streaming kernel IS enqueued: that kernel is what dirties the call's block and
     // clears the next one.  A call that fails between taking its block and that launch (a HIP error, the dev-build hook
     // P3D_TEST_FAIL_AFTER_LEASE) leaves the ring where it was: the next call takes the same, still clean block, and the
     // block after it is still waiting for a clearing kernel that will now be that call's.
-    void commit() {
+    void commit(bool hold = false) {
         if (ring) {
-            ring->cur = next;
-            ++ring->gen;
+            ring->next_slot = clears;
+            if (hold) ring->held |= 1u << take;
         }
     }
 };
 
-// the next block of the stream's ring (and the one after it in *zero_next, to be cleared by this call's kernel); the caller
-// commits the lease once its streaming kernel is enqueued
+// the block a starting call takes (and in *zero_next the one its kernel clears for the starting call after it); the caller
+// commits the lease once its streaming kernel is enqueued.  *block = nullptr (and P3D_OK) when every other block of the
+// ring is held: the caller then keeps its cursors in its workspace header.
 int cursor_block_for(hipStream_t st, RingLease* lease, u64** block, u64** zero_next) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
@@ -1634,7 +1648,8 @@ int cursor_block_for(hipStream_t st, RingLease* lease, u64** block, u64** zero_n
                 (void)hipFree(n->base);
                 return fail(P3D_EHIP, "hipMemsetAsync(cursor ring)%s");
             }
-            n->cur = kCursorRing - 1;
+            g_ring_bytes.fetch_add((int64_t)bytes, std::memory_order_relaxed);
+            n->next_slot = 0;
             g_rings[{dev, st}] = n;
             r = n;
         }
@@ -1642,9 +1657,25 @@ int cursor_block_for(hipStream_t st, RingLease* lease, u64** block, u64** zero_n
     lease->ring = r;
     lease->lock = std::unique_lock<std::mutex>(r->mu);
     if (!r->base) return fail(P3D_EINVAL, "the stream's state was released while a call on it was starting%s");
-    lease->next = (r->cur + 1) % kCursorRing;
-    *block = r->base + (size_t)lease->next * kRingSlotWords;
-    *zero_next = r->base + (size_t)((lease->next + 1) % kCursorRing) * kRingSlotWords;
+    lease->take = r->next_slot;
+    int zn = -1;
+    for (int k = 1; k < kCursorRing; ++k) {
+        const int sl = (lease->take + k) % kCursorRing;
+        if (!((r->held >> sl) & 1u)) {
+            zn = sl;
+            break;
+        }
+    }
+    if (zn < 0) {   // fifteen extractions hold a block each: this one keeps its cursors in its workspace header
+        lease->lock.unlock();
+        lease->ring.reset();
+        *block = nullptr;
+        *zero_next = nullptr;
+        return P3D_OK;
+    }
+    lease->clears = zn;
+    *block = r->base + (size_t)lease->take * kRingSlotWords;
+    *zero_next = r->base + (size_t)zn * kRingSlotWords;
     return P3D_OK;
 }
 
@@ -1655,6 +1686,7 @@ int free_ring(const std::shared_ptr<CursorRing>& r, bool stream_alive) {
     if (stream_alive) (void)hipStreamSynchronize(r->stream);
     const hipError_t e = hipFree(r->base);   // (hipFree itself waits for the device: safe even after the stream is gone)
     r->base = nullptr;
+    if (e == hipSuccess) g_ring_bytes.fetch_sub((int64_t)kCursorRing * kRingSlotWords * (int64_t)sizeof(u64), std::memory_order_relaxed);
     if (e != hipSuccess) return fail(P3D_EHIP, "hipFree(cursor ring): %s", hipGetErrorString(e));
     return P3D_OK;
 }
@@ -2020,6 +2052,12 @@ int emit_stream_impl(const T* grid, const Dims& d, const Ws& w, float thresh, co
     u64 *cursors = nullptr, *zero_next = nullptr;
     RingLease lease;   // (released when this function returns: both launches are enqueued by then)
     if (int rc = cursor_block_for(st, &lease, &cursors, &zero_next)) return rc;
+    if (!cursors) {   // (every block of the stream's ring is held by an extraction in several calls: the header's cursors,
+                      //  which this pass leaves with the values the counting pass left there)
+        cursors = hdr + H_CURSORS;
+        hipLaunchKernelGGL(k_zero_words, dim3((kCursorBlockWords + kBlock - 1) / kBlock), dim3(kBlock), 0, st, cursors,
+                           (int64_t)kCursorBlockWords);
+    }
     const bool timed = g_prof_mode != 0;
     if (timed) g_ev_used[ST_EMIT_VERTS] = true;
     dispatch_fused<T>(grid, d, thresh, 0, t, 0, bits, rec, cursors, zero_next, verts, 1u << 26,
@@ -2082,12 +2120,16 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
             return fail(P3D_EHIP, "injected failure between the cursor lease and the first launch (P3D_TEST_FAIL_AFTER_LEASE)%s");
 #endif
     } else if (continues) {
-        std::lock_guard<std::mutex> g(held->ring->mu);
-        if (held->ring->base != held->ring_base || held->ring->gen - held->gen > (uint64_t)(kCursorRing - 3))
-            return fail(P3D_EINVAL, "the cursor block part 1 took is gone: the stream's state was released, or more than 13 other "
-                                    "extractions started on the stream since%s");
+        // (the ring's lock from here to the last launch of this call, like a starting call: calls of one stream enqueue whole)
+        lease.ring = held->ring;
+        lease.lock = std::unique_lock<std::mutex>(held->ring->mu);
+        if (held->ring->base != held->ring_base || !((held->ring->held >> held->slot) & 1u))
+            return fail(P3D_EINVAL, "the cursor block part 1 took is gone: the stream's state was released "
+                                    "(p3d_mc_release_stream / p3d_mc_shutdown) since%s");
         cursors = held->cursors;
-    } else {
+        lease.ring.reset();   // (nothing to commit: the ring does not move for a continuing part)
+    }
+    if (!cursors) {   // no ring block (P3D_PARTS_RING=0, or every block of the ring is held): the workspace header's
         cursors = hdr + H_CURSORS;
         if (new_block)   // (an ordinary kernel: the runtime's fill path starts late, see fused_stack_impl)
             hipLaunchKernelGGL(k_zero_words, dim3((kCursorBlockWords + kBlock - 1) / kBlock), dim3(kBlock), 0, st, cursors,
@@ -2104,12 +2146,17 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
                           timed ? g_ev[stage][0] : nullptr, timed ? g_ev[stage][1] : nullptr, st);
         // (a launch that was refused never ran: the ring stays where it was)
         HIP_TRY(hipGetLastError());
-        lease.commit();
-        if (held && ring_block && part == 1) {   // the parts that continue the streaming find the block through the table
+        const bool holds = held && lease.ring && part == 1;   // the parts that continue the streaming find the block through the table
+        lease.commit(holds);
+        if (holds) {
             held->cursors = cursors;
             held->ring = lease.ring;
             held->ring_base = lease.ring->base;
-            held->gen = lease.ring->gen;
+            held->slot = lease.take;
+        } else if (continues && held) {
+            // the block goes back to its ring: stream order protects it until this launch is done (the lock is still ours)
+            if (held->ring->base == held->ring_base) held->ring->held &= ~(1u << held->slot);
+            *held = HeldBlock();
         }
     }
     if (part == 3) {
@@ -2335,6 +2382,7 @@ int proto_check(const ProtoCall& c, Extraction* out) {
         default: return fail(P3D_EINVAL, "bad slab part%s");
     }
     if (start) {
+        release_held(&e.held);   // (an extraction abandoned after its part 1: its cursor block goes back to the ring)
         e = Extraction();
         e.stream = c.stream;
         e.rx = c.rx; e.ry = c.ry; e.rz = c.rz; e.dtype = c.dtype; e.split = c.split;
@@ -2365,8 +2413,14 @@ void proto_commit(const void* ws, const Extraction& e_in) {
     if (g_proto.size() >= kMaxExtractions && g_proto.find({dev, ws}) == g_proto.end()) {
         // full: the older half goes in one sweep (amortised O(1) per call; entries are stamped with a running clock)
         const uint64_t keep_from = g_proto_clock > kMaxExtractions / 2 ? g_proto_clock - kMaxExtractions / 2 : 0;
-        for (auto it = g_proto.begin(); it != g_proto.end();)
-            it = it->second.last_use < keep_from ? g_proto.erase(it) : std::next(it);
+        for (auto it = g_proto.begin(); it != g_proto.end();) {
+            if (it->second.last_use < keep_from) {
+                release_held(&it->second.held);
+                it = g_proto.erase(it);
+            } else {
+                ++it;
+            }
+        }
     }
     Extraction e = e_in;
     e.last_use = ++g_proto_clock;
@@ -2636,12 +2690,13 @@ int p3d_mc_shutdown(void) {
 
 int p3d_mc_debug_counters(int64_t* out, int n) {
     if (!out || n < 0) return fail(P3D_EINVAL, "null pointer%s");
-    const int m = std::min(n, 6);
+    const int m = std::min(n, 7);
     for (int i = 0; i < std::min(m, 5); ++i) out[i] = g_counters[i].load(std::memory_order_relaxed);
     if (m > 5) {
         std::lock_guard<std::mutex> g(g_ring_mu);
         out[5] = (int64_t)g_rings.size();
     }
+    if (m > 6) out[6] = g_ring_bytes.load(std::memory_order_relaxed);
     return m;
 }
 

@@ -61,6 +61,39 @@ def test_dense_size_is_forgotten_after_four_sparse_frames(gpu, built):
     assert per_call[10] == (1, 1), per_call                              # four: forgotten (buffers shrink again) -> emitted twice
 
 
+@pytest.mark.parametrize("shape", [(72, 1024, 1024), (96, 1024, 512)])
+def test_a_surface_inside_one_band_of_y_tiles_spreads_over_all_cursor_groups(gpu, built, shape):
+    """A wall at a constant y in a 1024-wide grid (ncol = 172 / 86 tile columns: even, not a multiple of 8) lives in ONE of
+    the 8 y bands the XCDs own.  Until round 5 such a band reached 2 (4) of the 8 cursor groups, its 8 (16) regions filled
+    four times (twice) as fast as their share of the scratch allows, overflowed on every call, the field was streamed twice
+    and the adapter's slack doubled for good.  The cursor group now rotates with the slab: one pass per call,
+    from the first call on, and the slack stays where it was."""
+    from primitive3d_amd import capi
+    from tests.test_gpu_configs import torch_counts
+    rx, ry, rz = shape
+    y = torch.arange(ry, device=gpu, dtype=torch.float32)
+    # a wavy wall around y = 500: |y - 500.4| stays inside one band of 126 / 252 rows; x and z wiggle it by < 1 voxel
+    g = (y[None, :, None] - 500.4
+         + 0.3 * torch.sin(torch.arange(rx, device=gpu)[:, None, None] * 0.7)
+         + 0.3 * torch.cos(torch.arange(rz, device=gpu)[None, None, :] * 0.3)).contiguous()
+    want = torch_counts(g, 0.0)
+    assert want[0] > 32 * 8192 // 4   # enough vertices that 8 regions of the first call's scratch would not hold them
+    upper = [float(s_) for s_ in shape]
+    for i in range(3):
+        got, how = _call(built, g, upper)
+        assert got == want and how[0] == 1, (i, got, want, how)   # ONE streaming pass, every call
+    # and spread it is: no region of the (hinted) scratch overflowed on the way
+    ws = torch.empty(capi.workspace_bytes(*shape), dtype=torch.uint8, device=gpu)
+    v = torch.empty((want[0] + 64, 3), device=gpu)
+    f = torch.empty((want[1] + 64, 3), dtype=torch.int32, device=gpu)
+    capi.extract_fused_raw(g, 0.0, [0.0] * 3, upper, ws, v, f)
+    nv, nf, flags = capi.read_counts(ws, with_flags=True)
+    hdr = ws[:8192].view(torch.int64).cpu()
+    regions = hdr[32:32 + 32 * 16:16]   # the 32 region totals the finishing block leaves in the header
+    assert (nv, nf) == want and flags == 0 and int(regions.sum()) == nv
+    assert int((regions > 0).sum()) == 32 and int(regions.max()) < 3 * nv // 32, regions.tolist()
+
+
 def test_a_field_denser_than_the_scratch_is_streamed_twice(gpu, built):
     """White noise has a vertex on nearly every other edge: far beyond a vertex per 16 voxels.  Its first call overflows the
     scratch regions as well as the buffers, and only a second pass over the field (into exactly sized buffers) can help."""
@@ -121,12 +154,16 @@ def test_release_stream_keeps_device_memory_flat(gpu, built):
     torch.cuda.synchronize()
     rings = lambda: capi.debug_counters()["stream_rings"]
     rings0 = rings()
+    ring_bytes0 = capi.debug_counters()["ring_bytes"]
     free0 = torch.cuda.mem_get_info(gpu)[0]
     for _ in range(1000):
         job()
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info(gpu)[0]
     assert rings() == rings0   # every stream's ring went with p3d_mc_release_stream
+    # the rings' device memory itself, by the library's own account (out[6] of p3d_mc_debug_counters): freed, not only
+    # dropped from the map -- a ring is 64 KiB, so the free-memory figure below could not tell
+    assert capi.debug_counters()["ring_bytes"] == ring_bytes0, (capi.debug_counters(), ring_bytes0)
     # (memory: logged, with a generous one-sided bound -- other processes and earlier tests move the figure too)
     assert free0 - free1 <= 64 << 20, (free0, free1)
     # 100 streams alive at once, none released: their rings are there ...
@@ -134,13 +171,13 @@ def test_release_stream_keeps_device_memory_flat(gpu, built):
     for h in live:
         run_on(h)
     torch.cuda.synchronize()
-    assert rings() == rings0 + 100
+    assert rings() == rings0 + 100 and capi.debug_counters()["ring_bytes"] == ring_bytes0 + 100 * 16 * 4096
     # ... until they are released, one by one (the first half) or all at once by p3d_mc_shutdown (the rest)
     for h in live[:50]:
         capi.release_stream(h.value)
     assert rings() == rings0 + 50
     capi.shutdown()
-    assert rings() == 0
+    assert rings() == 0 and capi.debug_counters()["ring_bytes"] == 0
     for h in live:
         assert hip.hipStreamDestroy(h) == 0
     # and the library works again afterwards (its state is created on first use)

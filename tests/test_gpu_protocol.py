@@ -233,25 +233,45 @@ def test_the_table_holds_the_most_recent_workspaces(gpu):
 
 
 def test_part_1_keeps_its_cursor_block_while_others_start_on_the_stream(gpu):
-    """Part 1 takes a pre-cleared block of the stream's ring (no clearing kernel) and the parts that continue the streaming
-    use the same block; up to 13 other extractions may start on the stream in between -- each takes the next block --, as
-    the in-process multi-rank harness does.  More than that and the block has come round: refused, never garbage."""
+    """Part 1 takes a pre-cleared block of the stream's ring (no clearing kernel) and HOLDS it for the parts that continue
+    the streaming: other extractions that start on the stream in between -- the in-process multi-rank harness does exactly
+    that -- step over held blocks, however many of them start (until round 5 the held block was overrun after 13 starts and
+    the continuing part refused: ADVICE r05).  With fifteen blocks held a start keeps its cursors in its workspace header.
+    Only releasing the stream's state takes a held block away: refused then, never garbage."""
     r = Rig(gpu)
     other = Rig(gpu, shape=(12, 16, 70), seed=8)
     split = 16
     r.call(1, split=split, v=r.v)
-    for _ in range(13):
+    for _ in range(40):   # two and a half turns of the ring
         other.call(0, v=other.v, f=other.f)
+    _mesh_ok(other, other.v, other.f)
     r.call(3, split=split, v=r.v)
     r.call(4, v=r.v)
     assert r.capi.read_counts(r.ws) == (r.nv, r.nf)
     r.call(5, v=r.v, f=r.f)
     _mesh_ok(r, r.v, r.f)
-    r.fresh().call(1, split=split, v=r.v)
-    for _ in range(14):
+    # twenty extractions between their part 1 and part 2 at once (world = 20 in one process): fifteen hold a ring block,
+    # the rest keep their cursors in their headers; whole-grid calls run in between; every one finishes with the right mesh
+    many = [Rig(gpu) for _ in range(20)]
+    for m in many:
+        m.call(1, split=split, v=m.v)
         other.call(0, v=other.v, f=other.f)
+    for m in reversed(many):
+        m.call(2, split=split, v=m.v, f=m.f)
+        other.call(0, v=other.v, f=other.f)
+    for m in many[::7]:
+        _mesh_ok(m, m.v, m.f)
+    _mesh_ok(other, other.v, other.f)
+    # the blocks are free again: a whole turn of the ring by plain calls, then a held one that is taken away
+    for _ in range(20):
+        other.call(0, v=other.v, f=other.f)
+    r.fresh().call(1, split=split, v=r.v)
+    torch.cuda.synchronize()
+    r.capi.release_stream(torch.cuda.current_stream().cuda_stream)
     with pytest.raises(r.capi.P3DError, match="cursor block part 1 took is gone"):
         r.call(2, split=split, v=r.v, f=r.f)
+    r.call(0, v=r.v, f=r.f)   # (a start is always legal; the stream's state is created again)
+    _mesh_ok(r, r.v, r.f)
     torch.cuda.synchronize()
 
 
