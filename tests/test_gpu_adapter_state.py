@@ -61,7 +61,7 @@ def test_dense_size_is_forgotten_after_four_sparse_frames(gpu, built):
     assert per_call[10] == (1, 1), per_call                              # four: forgotten (buffers shrink again) -> emitted twice
 
 
-@pytest.mark.parametrize("shape", [(72, 1024, 1024), (96, 1024, 512)])
+@pytest.mark.parametrize("shape", [(72, 1024, 1024), (160, 1024, 512)])
 def test_a_surface_inside_one_band_of_y_tiles_spreads_over_all_cursor_groups(gpu, built, shape):
     """A wall at a constant y in a 1024-wide grid (ncol = 172 / 86 tile columns: even, not a multiple of 8) lives in ONE of
     the 8 y bands the XCDs own.  Until round 5 such a band reached 2 (4) of the 8 cursor groups, its 8 (16) regions filled
