@@ -71,8 +71,13 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     TORCH_CHECK(density_grid.is_contiguous(), "density_grid must be contiguous");
     TORCH_CHECK(density_grid.ndimension() == 3);
     TORCH_CHECK(lower.size() == 3 && upper.size() == 3, "lower and upper must have 3 elements");
-    TORCH_CHECK(density_grid.scalar_type() == torch::kFloat, "expected scalar type Float but found ",
+    // float32 as in the reference (data_ptr<float>() throws there on anything else, :243) -- and float16, which the reference's
+    // wrapper would have up-cast before it got here (marching_cubes.py:87): the library reads it as it is (half the bytes,
+    // no copy) and compares exactly like the up-cast (`float(v) > thresh`), so the mesh is the one the up-cast gives
+    const bool half_grid = density_grid.scalar_type() == torch::kHalf;
+    TORCH_CHECK(half_grid || density_grid.scalar_type() == torch::kFloat, "expected scalar type Float but found ",
                 density_grid.scalar_type());
+    const int dtype = half_grid ? P3D_F16 : P3D_F32;
 
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(density_grid.device());
     void* stream = (void*)c10::hip::getCurrentHIPStream(density_grid.device().index()).stream();
@@ -84,7 +89,7 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     Tensor ws = torch::empty({(int64_t)ws_bytes}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
     const auto vopt = torch::TensorOptions().dtype(torch::kFloat).device(dev);
     const auto fopt = torch::TensorOptions().dtype(torch::kInt).device(dev);
-    const float* grid = density_grid.data_ptr<float>();
+    const void* grid = density_grid.data_ptr();
     Tensor vertices, faces;
     int64_t nv = 0, nf = 0;
 
@@ -128,7 +133,7 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
             vertices = torch::empty({capv, 3}, vopt);
         }
         if (capf > 0) faces = torch::empty({capf, 3}, fopt);
-        check_rc(p3d_mc_extract_fused(grid, P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, nullptr,
+        check_rc(p3d_mc_extract_fused(grid, dtype, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, nullptr,
                                       ws.data_ptr(), capv ? vertices.data_ptr<float>() : nullptr, capv,
                                       capv ? scratch.data_ptr<float>() : nullptr, scratch_rows,
                                       capf ? faces.data_ptr<int32_t>() : nullptr, capf, stream),
@@ -174,7 +179,7 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
         p3d_mc_slab parts{};
         parts.part = 3;
         auto call = [&](float* v, int64_t cv, int32_t* f, int64_t cf) {
-            check_rc(p3d_mc_extract_fused(grid, P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, &parts,
+            check_rc(p3d_mc_extract_fused(grid, dtype, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, &parts,
                                           ws.data_ptr(), v, cv, scratch.data_ptr<float>(), scratch_rows, f, cf, stream),
                      "p3d_mc_extract_fused");
         };
@@ -226,7 +231,7 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
         faces = torch::empty({nf, 3}, fopt);
         p3d_mc_slab again{};
         again.part = 6;
-        check_rc(p3d_mc_extract_fused(grid, P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, &again,
+        check_rc(p3d_mc_extract_fused(grid, dtype, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, &again,
                                       ws.data_ptr(), vertices.data_ptr<float>(), nv, scratch.data_ptr<float>(), scratch_rows,
                                       nf ? faces.data_ptr<int32_t>() : nullptr, nf, stream),
                  "p3d_mc_extract_fused");
@@ -239,13 +244,13 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
             // a region numbered more than 2^26 vertices: the one-pass ids are ambiguous -> dense ids by the
             // scan-numbered counting call (include/p3d_mc.h: p3d_mc_read_counts, bit 1; p3d_mc_count_scan)
             if (id_overflow) {
-                check_rc(p3d_mc_count_scan(grid, P3D_F32, rx, ry, rz, thresh, nullptr, ws.data_ptr(), stream), "p3d_mc_count_scan");
+                check_rc(p3d_mc_count_scan(grid, dtype, rx, ry, rz, thresh, nullptr, ws.data_ptr(), stream), "p3d_mc_count_scan");
                 check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, nullptr, stream), "p3d_mc_read_counts");
             }
             // pathological region imbalance: the gather emitter writes by vertex id and cannot overflow
             vertices = torch::empty({nv, 3}, vopt);
             faces = torch::empty({nf, 3}, fopt);
-            check_rc(p3d_mc_emit(grid, P3D_F32, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, nullptr,
+            check_rc(p3d_mc_emit(grid, dtype, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, nullptr,
                                  ws.data_ptr(), nv ? vertices.data_ptr<float>() : nullptr, nv,
                                  nf ? faces.data_ptr<int32_t>() : nullptr, nf, nullptr, stream),
                      "p3d_mc_emit");

@@ -52,10 +52,15 @@ def _via_pymcubes(density_grid, thresh, lower, upper):
 
 def _on_device_as_float32(density_grid):
     """ndarray -> tensor -> device -> float32 (:84-87; a non-contiguous tensor stays non-contiguous and is rejected
-    by the native module, like in the reference); grids thinner than 2 samples along any axis: bare ValueError."""
+    by the native module, like in the reference); grids thinner than 2 samples along any axis: bare ValueError.
+    A float16 grid stays float16: the native module reads it as it is and classifies it exactly like its up-cast
+    (`float(v) > thresh`, the conversion is exact), so the mesh is the one the reference's `.to(torch.float32)` gives --
+    without the copy and with half the bytes read."""
     if isinstance(density_grid, np.ndarray):
         density_grid = torch.tensor(density_grid)
-    density_grid = density_grid.cuda().to(torch.float32)
+    density_grid = density_grid.cuda()
+    if density_grid.dtype != torch.float16:
+        density_grid = density_grid.to(torch.float32)
     if min(density_grid.shape[0], density_grid.shape[1], density_grid.shape[2]) < 2:
         raise ValueError()
     return density_grid

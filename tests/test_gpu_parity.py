@@ -255,6 +255,28 @@ def test_pybind_module_matches_oracle(gpu, built):
     assert np.array_equal(soup(v.cpu().numpy(), f.cpu().numpy()), soup(rv, rf))
 
 
+def test_fp16_grid_through_the_wrapper(gpu, built):
+    """prim3d.marching_cubes on a float16 grid: the reference's wrapper up-casts it (marching_cubes.py:87) and its C++ entry
+    sees float32; here the grid stays float16 all the way into the kernel (half the bytes, no copy).  Same mesh as the
+    up-cast -- against the oracle on `grid.float()` and against this module's own float32 call; other dtypes still go
+    through float32, and the native module still refuses what the reference's data_ptr<float>() would."""
+    g16 = small_cases()["perlin48"][0].astype(np.float16)
+    t16 = torch.from_numpy(g16).to(gpu)
+    p0 = torch.cuda.memory_allocated(gpu)
+    v, f = built.marching_cubes(t16, 0.01)
+    v32, f32 = built.marching_cubes(t16.float(), 0.01)
+    rv, rf, _ = oracle_extract(g16.astype(np.float32), 0.01)
+    soup = lambda vv, ff: np.sort(vv[ff.astype(np.int64)].reshape(len(ff), 9).view([("", np.float32)] * 9), axis=0)
+    assert v.dtype == torch.float32 and f.dtype == torch.int32 and v.shape == rv.shape and f.shape == rf.shape
+    assert np.array_equal(soup(v.cpu().numpy(), f.cpu().numpy()), soup(rv, rf))
+    assert np.array_equal(soup(v32.cpu().numpy(), f32.cpu().numpy()), soup(rv, rf))
+    with pytest.raises(RuntimeError, match="expected scalar type Float but found Double"):
+        built.libPrim3D.marching_cubes(t16.double(), 0.0, [0.0] * 3, [48.0] * 3)
+    vd, fd = built.marching_cubes(t16.double(), 0.01)   # (the wrapper converts every other dtype, as the reference does)
+    assert vd.shape == rv.shape and fd.shape == rf.shape
+    del p0
+
+
 def test_reference_example_counts(gpu, built):
     """examples/sphere.py:8-15 through the Python wrapper: int64 grid, thresh 0 -> 11766 / 23528."""
     from primitive3d_amd.fields import sphere_grid

@@ -64,7 +64,15 @@ def test_marching_cubes_wrapper(wrapper, rec):
     else:
         with contextlib.redirect_stdout(buf):
             v, f = w.marching_cubes(eval(rec["grid"]), eval(rec["thresh"]), **kw)
-        assert calls[0] == rec["call"]
+        want = dict(rec["call"])
+        if rec["name"] == "f16_tensor":
+            # the ONE deliberate difference at the native boundary: the reference up-casts a float16 grid before its C++
+            # entry sees it (marching_cubes.py:87); here it stays float16 -- the HIP library reads fp16 natively and
+            # classifies exactly like the up-cast (tests/test_gpu_parity.py::test_fp16_grid_through_the_wrapper), so the
+            # result is the same mesh without the copy
+            assert want["dtype"] == "torch.float32"
+            want["dtype"] = "torch.float16"
+        assert calls[0] == want
     assert buf.getvalue() == rec["stdout"]
 
 
