@@ -1,9 +1,10 @@
-"""dev: randomized parity fuzz of the one-pass and the counting call against the oracle (small random shapes)."""
+"""dev: randomized parity fuzz of the one-pass call, the scan-numbered pair and the two-pass pair (p3d_mc_count +
+p3d_mc_emit) against the oracle (small random shapes)."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import numpy as np, torch
 from oracle import oracle_extract
-from tests.test_gpu_parity import _assert_same_mesh, _hip_extract, _hip_extract_fused
+from tests.test_gpu_parity import _assert_same_mesh, _hip_extract, _hip_extract_fused, _hip_extract_pair
 rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
 gpu = torch.device("cuda", 0)
 n_ok = 0
@@ -32,5 +33,6 @@ for it in range(int(os.environ.get("N", "60"))):
         ref = oracle_extract(g, thresh)
     _assert_same_mesh(_hip_extract_fused(gpu, g, thresh, None, None, dtype=dt), ref)
     _assert_same_mesh(_hip_extract(gpu, g, thresh, None, None, dtype=dt), ref)
+    _assert_same_mesh(_hip_extract_pair(gpu, g, thresh, None, None, dtype=dt), ref)   # (count-only pass + second streaming pass)
     n_ok += 1
 print("fuzz ok:", n_ok, "cases")
