@@ -232,10 +232,11 @@ def rank_slab_workload(capi, perlin_grid, dev, world=8, rank=3, shape=(1024, 102
                     o.tensor.copy_(rec_src[o.tensor.numel()])
         return []
 
-    def _all_gather(out_t, inp):
+    def _all_gather(out_t, inp, async_op=False):
         # (ONE device copy, like the collective it stands in for: every row receives this rank's header words -- the other
         #  ranks' counts would arrive here; similar slabs have similar counts, so the id bases are realistic)
         out_t.view(world, -1).copy_(inp.view(1, -1).expand(world, -1))
+        return None   # (the asynchronous form's work object: nothing to wait for, the copy is in stream order)
 
     saved = {k: getattr(dist, k, None) for k in ("get_backend", "P2POp", "batch_isend_irecv", "all_gather_into_tensor", "isend", "irecv")}
     try:

@@ -406,16 +406,22 @@ class SlabExtractor:
             send_buf = self.records_send_buffer()  # (kept referenced until the transfer has completed)
             self._mark("last planes streamed + record export")
             pre_comm()
-            dist.all_gather_into_tensor(rank_counts.view(-1), be.header_words())
-            counts_ready = torch.cuda.Event() if self.grid.is_cuda else None
-            if counts_ready is not None:
-                counts_ready.record()
+            # ASYNCHRONOUS: the plain form makes the current stream wait for the collective right here (torch's non-async
+            # collectives end in work.wait()), i.e. the face count below would start only when the slowest rank's count had
+            # arrived -- the all-gather's latency and the ranks' skew on every rank's critical path.  Waited for in front
+            # of the face launch, the only consumer (round 6: it had been the plain form since round 3).
+            gathered = dist.all_gather_into_tensor(rank_counts.view(-1), be.header_words(), async_op=True)
             self._mark("all-gather of vertex counts")
             rec_works = shift_to_prev(send_buf, self.records_recv_buffer())
             be.launch_finalize(defer_totals=True)   # (from the second call on: the faces follow with a capacity guess)
             self._mark("face count + early vertex copy")
             for w in rec_works:
                 w.wait()
+            if gathered is not None:
+                gathered.wait()   # (a stream-level wait under RCCL: the host goes on)
+            counts_ready = torch.cuda.Event() if self.grid.is_cuda else None
+            if counts_ready is not None:
+                counts_ready.record()
             self._mark("halo records received (wait)")
             del send_buf
             self._nv, self._nf, self._verts, faces = be.finish_on_device(rank_counts, self.rank)
