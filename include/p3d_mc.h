@@ -121,6 +121,17 @@ typedef struct p3d_mc_slab {
                                     capacity guess before it has seen the totals (SlabExtractor's device path): one launch
                                     less on the stream per extraction */
     int32_t reserved;            /* 0 */
+    const uint32_t* region_first_rows; /* part 0 without a halo plane only (ABI v10), optional HOST pointer to 33 ascending row
+                                    numbers, [0] = 0, [32] <= cap_vertices: a PREDICTED LAYOUT of the streaming kernel's 32
+                                    output regions inside `vertices` -- region r owns rows [r], [r+1]) -- made by the caller
+                                    from the region totals of its last call on the shape (p3d_mc_read_counts_ex) plus slack.
+                                    The kernel then stores every vertex at its region's first row + slot: its final row unless
+                                    that row lies at or beyond V; the few rows that do are moved into the free rows the slack
+                                    left below V, and the face kernel translates their ids.  No scratch buffer (vertex_scratch
+                                    may be NULL), no second trip for the other rows.  A region that outgrows its rows sets bit 2
+                                    of the flags: the vertex buffer is incomplete, call p3d_mc_emit with exactly sized buffers
+                                    (a second pass over the field).  Behind such a call p3d_mc_emit takes both buffers, or
+                                    faces alone; part 6 is not available. */
 } p3d_mc_slab;
 
 /* Bytes of device scratch p3d_mc_count / p3d_mc_emit need for an [rx,ry,rz] grid.
@@ -160,6 +171,12 @@ int p3d_mc_count_scan(const void* grid, int dtype, int64_t rx, int64_t ry, int64
  *          p3d_mc_count_scan (dense ids by prefix scan) and then call p3d_mc_emit. */
 int p3d_mc_read_counts(const void* ws, int64_t* num_vertices, int64_t* num_faces, int32_t* scratch_overflow,
                        void* stream);
+/* The same, and the totals of the streaming kernel's 32 output regions (region_totals: 32 int64, nullable) -- what a caller
+ * lays the next call's regions out from (p3d_mc_slab.region_first_rows).  They come with the totals (same mailbox slot) after a
+ * whole-grid p3d_mc_extract_fused (part 0) or p3d_mc_count; after other calls they are unspecified.  scratch_overflow also
+ * carries bit 2 (4): a region outgrew its rows of the predicted layout. */
+int p3d_mc_read_counts_ex(const void* ws, int64_t* num_vertices, int64_t* num_faces, int32_t* scratch_overflow,
+                          int64_t* region_totals, void* stream);
 
 /* Phase 2 (replaces gen_vertices_kernel, gen_faces_kernel and the epilogue, marching_cubes.cu:266-298):
  * write vertices [V,3] f32 already mapped to the bounding box (v * scale + lower, scale as in

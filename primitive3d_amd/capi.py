@@ -13,7 +13,7 @@ P3D_ERANGE = -2
 
 # every symbol include/p3d_mc.h declares
 SYMBOLS = ("p3d_mc_abi_version", "p3d_last_error", "p3d_mc_workspace_bytes", "p3d_mc_count", "p3d_mc_count_scan",
-           "p3d_mc_read_counts", "p3d_mc_emit", "p3d_mc_plane_records", "p3d_mc_export_plane_records", "p3d_mc_profile_enable",
+           "p3d_mc_read_counts", "p3d_mc_read_counts_ex", "p3d_mc_emit", "p3d_mc_plane_records", "p3d_mc_export_plane_records", "p3d_mc_profile_enable",
            "p3d_mc_profile_read", "p3d_mc_profile_stage_name", "p3d_mc_extract_fused", "p3d_mc_debug_layout",
            "p3d_mc_workspace_bytes_batched", "p3d_mc_extract_fused_batched", "p3d_mc_reload_tuning",
            "p3d_mc_debug_counters", "p3d_mc_release_stream", "p3d_mc_shutdown", "p3d_mc_dev_hooks")
@@ -24,7 +24,8 @@ class Slab(ctypes.Structure):
     _fields_ = [("halo_last_plane", c_int32), ("part", c_int32), ("vertex_id_base", c_int64),
                 ("halo_vertex_id_base", c_int64), ("x_origin", c_int64), ("split_plane", c_int64),
                 ("rank_counts", c_void_p), ("rank", c_int32), ("rank_counts_stride", c_int32),
-                ("export_first_plane_to", c_void_p), ("defer_totals", c_int32), ("reserved", c_int32)]
+                ("export_first_plane_to", c_void_p), ("defer_totals", c_int32), ("reserved", c_int32),
+                ("region_first_rows", c_void_p)]
 
 
 class P3DError(RuntimeError):
@@ -48,6 +49,8 @@ def lib():
         L.p3d_mc_count.argtypes = [c_void_p, c_int, c_int64, c_int64, c_int64, c_float, POINTER(Slab), c_void_p, c_void_p]
         L.p3d_mc_count_scan.argtypes = L.p3d_mc_count.argtypes
         L.p3d_mc_read_counts.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32), c_void_p]
+        L.p3d_mc_read_counts_ex.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32), POINTER(c_int64 * 32),
+                                            c_void_p]
         L.p3d_mc_emit.argtypes = [c_void_p, c_int, c_int64, c_int64, c_int64, c_float, POINTER(c_float * 3),
                                   POINTER(c_float * 3), POINTER(c_int64 * 3), POINTER(Slab), c_void_p, c_void_p,
                                   c_int64, c_void_p, c_int64, c_void_p, c_void_p]
@@ -132,6 +135,25 @@ def read_counts(ws, with_flags=False):
     return (v.value, f.value, int(o.value)) if with_flags else (v.value, f.value)
 
 
+def read_counts_ex(ws):
+    """p3d_mc_read_counts_ex: (V, F, flags, [32 region totals of the streaming kernel])."""
+    nv, nf, over = c_int64(0), c_int64(0), c_int32(0)
+    reg = (c_int64 * 32)()
+    with _on_device_of(ws):
+        _check(lib().p3d_mc_read_counts_ex(c_void_p(ws.data_ptr()), byref(nv), byref(nf), byref(over), byref(reg), _stream_ptr(ws)),
+               "p3d_mc_read_counts_ex")
+    return nv.value, nf.value, over.value, list(reg)
+
+
+def region_layout(region_totals, slack_num=1, slack_den=24, pad=128):
+    """33 ascending first rows for p3d_mc_slab.region_first_rows from the region totals of an earlier call: every region gets its
+    total + total * slack_num / slack_den + pad rows.  Returns (ctypes uint32 array to keep alive, rows the vertex buffer needs)."""
+    first = [0]
+    for n in region_totals:
+        first.append(first[-1] + int(n) + int(n) * slack_num // slack_den + pad)
+    return (ctypes.c_uint32 * 33)(*first), first[-1]
+
+
 def emit(grid, thresh, lower, upper, ws, vertices, faces, vertex_keys=None, slab=None, full_res=None):
     rx, ry, rz = grid.shape
     lo = (c_float * 3)(*[float(v) for v in lower])
@@ -196,7 +218,7 @@ def extract_fused_raw(grid, thresh, lower, upper, ws, vertices, faces, slab=None
     `scratch` ([rows,3] f32) is required when `vertices` is given; allocated here if omitted.  (Parts 3 and 4 of an
     extraction in several calls -- p3d_mc_slab.part -- take the scratch without a vertex buffer.)"""
     import torch
-    if vertices is not None and vertices.shape[0] and scratch is None:
+    if vertices is not None and vertices.shape[0] and scratch is None and not (slab is not None and slab.region_first_rows):
         scratch = torch.empty((scratch_rows_for(vertices.shape[0]), 3), dtype=torch.float32, device=grid.device)
     rx, ry, rz = grid.shape
     lo = (c_float * 3)(*[float(v) for v in lower])

@@ -94,8 +94,13 @@ constexpr int kPreMinChunks = 1024;   // more face chunks than this: a one-block
 constexpr int kHdrBytes = 8192;   // [0,256) totals/flags; [256,4352) the 32 cursors of a multi-part extraction (a whole-grid
                                   // call uses a block of the library's ring, see cursor_block_for); [4352,4608) prefixes
 // header slots (u64)
-enum { H_V = 0, H_T = 1, H_FLAGS = 2, H_RECFORM = 3 /* 1: rec[].x still region * 2^26 + slot */,
-       H_CURSORS = 32 /* u64 index */, H_PREFIX = 32 + 32 * 16 };
+enum { H_V = 0, H_T = 1, H_FLAGS = 2, H_RECFORM = 3 /* 1: rec[].x still region * 2^26 + slot; 2: rec[].x is a row of the
+                                                         region layout, rows at or beyond V are remapped (H_TAIL_*) */,
+       H_CURSORS = 32 /* u64 index */, H_PREFIX = 32 + 32 * 16,
+       H_LAYOUT = 600 /* [33] first row of every region (+ the end), copied there by the streaming kernel */,
+       H_TAIL_TS = 640 /* [32] first row at or beyond V of region r */, H_TAIL_TP = 672 /* [32] such rows in regions < r */,
+       H_TAIL_HS = 704 /* [32] first free row below V behind region r */, H_TAIL_HP = 736 /* [33] free rows behind regions < r */,
+       H_TAIL_TE = 776 /* [32] end of region r's rows at or beyond V (= ts_r when it has none) */ };
 
 __host__ __device__ inline Dims make_dims(int64_t rx, int64_t ry, int64_t rz) {
     Dims d;
@@ -314,6 +319,10 @@ __device__ inline void mb_publish_v(u64* slot, u64 seq, u64 nv, u64 flags) {
     __hip_atomic_store(slot + 2, flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(slot + 0, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// (the 32 region totals of the streaming kernel travel in the same slot, words 8..39: written before the sequence word)
+__device__ inline void mb_put_region(u64* slot, int r, u64 n) {
+    if (slot) __hip_atomic_store(slot + 8 + r, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ inline void mb_publish_f(u64* slot, u64 seq, u64 nf) {
     if (!slot) return;
     __hip_atomic_store(slot + 4, nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -472,7 +481,8 @@ __global__ void __launch_bounds__(kBlock) k_emit_vertices(const T* __restrict__ 
 struct FaceArgs {
     int xlate;  // rec[].x may be region * 2^26 + slot (straight from the streaming kernel) and is made dense on the fly:
                 // 0 never; 1 yes, region bases from the call's cursors (the header is not finished yet);
-                // 2 if hdr[H_RECFORM] says so, region bases from hdr[H_PREFIX] (a later p3d_mc_emit)
+                // 2 what hdr[H_RECFORM] says (a later p3d_mc_emit / part 6): region bases from hdr[H_PREFIX], or layout form;
+                // 3 layout form (RegionLayout): rec[].x is a row; rows at or beyond V are remapped with the header's tail tables
     int halo_last;
     int64_t vid_base, halo_vid_base;
     const int64_t* rank_counts;  // optional: all-gathered V of all ranks on the device; the id bases are derived from it
@@ -520,9 +530,179 @@ struct CompactArgs {
     u32 id_limit;          // vertices a region may number (2^26: ids are region * 2^26 + slot); beyond it ids alias
     int nitems;            // items of a stack (0 / 1: a single grid)
     int64_t* item_offsets; // (unused by the riding blocks; kept so that both call flavours build one argument struct)
+    int layout = 0;        // region-layout mode (RegionLayout).  In the COUNTING launch the riding blocks are layout_move_block -- block 0
+                           // makes V, the flags and the tail tables, every block moves one region's rows at or beyond V into the
+                           // free rows below V --, in the FACE launch the one extra block is layout_report_block: F and the report
+                           // to the host (V, flags, region totals)
 };
 typedef float F4U __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access at 4-byte alignment
 typedef float F4A __attribute__((ext_vector_type(4)));
+// Region-layout mode (RegionLayout, fused_stream.inc).  Occupied rows: O = union of [first_r, first_r + n_r); V = sum n_r.
+// Rows of O at or beyond V ("tail": what the slack between the regions pushed out) move into the free rows below V
+// ("holes"), k-th tail row -> k-th hole, both in ascending order -- one interval of each kind per region:
+//     tail of region r  [ts_r, ts_r + tl_r) = [max(first_r, V), max(first_r + n_r, V))        tp_r = tail rows of regions < r
+//     hole behind r     [hs_r, hs_r + hl_r) = [min(first_r + n_r, V), min(first_(r+1), V))    hp_r = hole rows behind regions < r
+// (n_r clipped to the region's rows: a region that outgrew them sets flag 4 and the caller re-emits).  Every block works the
+// tables out for itself from the 32 cursors and the layout the streaming kernel left in the header; block 0 writes them
+// there for k_faces (and for tests/ws_keys.py); block j moves region j's tail rows.
+struct TailTables {
+    u32 V, ts, tl, tp, hs, hl, hp;   // lane r < 32: region r's entries
+};
+__device__ inline TailTables tail_tables(const u64* __restrict__ cursors, const u64* __restrict__ hdr_layout, u32* over_out) {
+    const int lane = threadIdx.x & 63;
+    const bool mine = lane < kRegions;
+    const u32 first = mine ? (u32)hdr_layout[lane] : 0u, next = mine ? (u32)hdr_layout[lane + 1] : 0u;
+    const u64 cur = mine ? cursors[lane * kCursorStride] : 0ull;
+    const u32 rows = next - first;
+    const u32 n = (u32)min(cur, (u64)rows);   // rows the region really holds
+    if (over_out) *over_out = (__ballot(cur > (u64)rows) != 0ull) ? 1u : 0u;
+    u64 v64 = cur;   // V counts every vertex, stored or not (the caller sizes its re-emission from it)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v64 += __shfl_xor(v64, o, 64);
+    TailTables t;
+    t.V = (u32)min(v64, (u64)0xffffffffull);
+    const u32 end = first + n;
+    t.ts = max(first, t.V);
+    t.tl = max(end, t.V) - t.ts;
+    t.hs = min(end, t.V);
+    t.hl = mine ? min(next, t.V) - t.hs : 0u;
+    if (!mine) t.tl = 0u;
+    t.tp = wave_prefix_sum(t.tl) - t.tl;
+    t.hp = wave_prefix_sum(t.hl) - t.hl;
+    return t;
+}
+// dense row of a row at or beyond V: lane-held tables (lane r = region r), looked up with ds_bpermute (ALL lanes active).
+// *region receives the region the row lies in.
+__device__ inline u32 tail_remap(u32 row, const TailTables& t, u32 lay_first /* lane r <= 32: first_r, else ~0 */, u32* region = nullptr) {
+    // region of the row: the last r with first_r <= row (first_ is strictly ascending, first_0 = 0)
+    u32 j = 0;
+#pragma unroll
+    for (int h = 16; h >= 1; h >>= 1) {
+        const u32 f = (u32)__builtin_amdgcn_ds_bpermute((int)((j + h) << 2), (int)lay_first);
+        j = (f <= row) ? j + h : j;
+    }
+    if (region) *region = j;
+    const u32 tsj = (u32)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)t.ts);
+    const u32 tpj = (u32)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)t.tp);
+    const u32 k = tpj + (row - tsj);
+    // hole interval: the LAST i with hp_i <= k (hp_ is non-decreasing: empty intervals are stepped over)
+    u32 i = 0;
+#pragma unroll
+    for (int h = 16; h >= 1; h >>= 1) {
+        const u32 hpv = (u32)__builtin_amdgcn_ds_bpermute((int)((i + h) << 2), (int)t.hp);
+        i = (hpv <= k) ? i + h : i;
+    }
+    const u32 hsi = (u32)__builtin_amdgcn_ds_bpermute((int)(i << 2), (int)t.hs);
+    const u32 hpi = (u32)__builtin_amdgcn_ds_bpermute((int)(i << 2), (int)t.hp);
+    return hsi + (k - hpi);
+}
+// the tail tables as the counting launch's block 0 left them in the header (lane r < 32: region r); *tail_end: lane r = the
+// end of region r's rows at or beyond V
+__device__ inline TailTables tail_tables_from_header(const u64* __restrict__ hdr, u32 V, u32* lay_first, u32* tail_end) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane & (kRegions - 1);
+    auto ld = [&](int idx) { return (u32)__hip_atomic_load(hdr + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    TailTables t{};
+    t.V = V;
+    t.ts = ld(H_TAIL_TS + r);
+    t.tp = ld(H_TAIL_TP + r);
+    t.hs = ld(H_TAIL_HS + r);
+    t.hp = ld(H_TAIL_HP + r);
+    *tail_end = ld(H_TAIL_TE + r);
+    const u32 lf = ld(H_LAYOUT + min(lane, kRegions));
+    *lay_first = lane <= kRegions ? lf : 0xffffffffu;
+    if (lane >= kRegions) {   // (never selected: the searches stay below 32)
+        t.ts = t.tp = t.hp = 0xffffffffu;
+        t.hs = 0u;
+    }
+    return t;
+}
+constexpr u32 kTailMark = 0x80000000u;   // a staged base whose ids may straddle a cut of the remap: translated id by id
+// A staged unit's first id in layout form -> its dense first id, or -- the unit's run of at most 192 ids may cross V or the
+// end of a hole -- the row itself with kTailMark: its ids are then translated one by one.  ALL lanes must be active.
+__device__ inline u32 tail_unit(u32 row, const TailTables& t, u32 lay_first, u32 tail_end, u32* strad) {
+    const u32 V = t.V;
+    u32 j = 0;
+    const u32 r0 = tail_remap(row, t, lay_first, &j);
+    const u32 te = (u32)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)tail_end);
+    const u32 last = min(row + 191u, te - 1u);                    // the run cannot leave its region's rows
+    const u32 r1 = tail_remap(max(last, row), t, lay_first);
+    const bool fin = row + 191u < V || row + 191u < row;          // wholly below V (or garbage that wrapped: never used)
+    const bool crossV = !fin && row < V;
+    // inside ONE region's tail the rows' order numbers are consecutive, the map is strictly increasing: equal spans = a shift
+    const bool whole = !fin && !crossV && last >= row && (r1 - r0 == last - row);
+    const bool marked = !fin && !whole;
+    if (marked) *strad = 1u;
+    return fin ? row : (whole ? r0 : (row | kTailMark));
+}
+// the face launch's one extra block in layout mode: F, and the report to the host (V and the flags were left in the header by
+// the counting launch's block 0; the 32 region totals travel with them: the adapter lays the next call out from them)
+__device__ inline void layout_report_block(const CompactArgs& c, u64* __restrict__ hdr, u64* mb, u64 seq, u64* smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (blockIdx.x != 0) return;
+    u64 part_sum = 0;
+    for (int i = tid; i < c.nchunks; i += kBlock) part_sum += c.chunk_sum[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part_sum += __shfl_down(part_sum, o, 64);
+    if (lane == 0) smem[tid >> 6] = part_sum;
+    __syncthreads();
+    if (tid < kRegions) mb_put_region(mb, tid, c.cursors[tid * kCursorStride]);
+    if (tid == 0) {
+        const u64 nf = smem[0] + smem[1] + smem[2] + smem[3];
+        hdr[H_T] = nf;
+        mb_publish_f(mb, seq, nf);
+        mb_publish_v(mb, seq, hdr[H_V], hdr[H_FLAGS]);   // (a release store: the region totals of this wave's lanes go first)
+    }
+}
+// the counting launch's riding blocks in layout mode: block 0 writes V, the flags and the tail tables; block j moves region
+// (j mod 32)'s rows at or beyond V into the holes
+__device__ inline void layout_move_block(const CompactArgs& c, u64* __restrict__ hdr) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    u32 over = 0;
+    const TailTables t = tail_tables(c.cursors, hdr + H_LAYOUT, &over);   // (every wave of every block: 32 + 33 loads)
+    const u32 lay_first = lane <= kRegions ? (u32)hdr[H_LAYOUT + lane] : 0xffffffffu;
+    if (blockIdx.x == 0 && tid < 64) {
+        if (lane < kRegions) {
+            hdr[H_TAIL_TS + lane] = t.ts;
+            hdr[H_TAIL_TP + lane] = t.tp;
+            hdr[H_TAIL_HS + lane] = t.hs;
+            hdr[H_TAIL_HP + lane] = t.hp;
+            hdr[H_TAIL_TE + lane] = t.ts + t.tl;
+        }
+        const u64 cur = lane < kRegions ? c.cursors[lane * kCursorStride] : 0ull;
+        // (what a later p3d_mc_emit reads: the region totals and their prefix, as the scratch mode leaves them)
+        if (lane < kRegions && c.cursors != hdr + H_CURSORS) hdr[H_CURSORS + lane * kCursorStride] = cur;
+        u64 inc = cur;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u64 tt = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += tt;
+        }
+        if (lane < kRegions) hdr[H_PREFIX + lane] = inc - cur;
+        if (lane == kRegions - 1) {
+            hdr[H_TAIL_HP + kRegions] = t.hp + t.hl;
+            hdr[H_V] = inc;
+            hdr[H_FLAGS] = (over ? 4ull : 0ull) | (inc > 0x7fffffffull ? 2ull : 0ull);
+            hdr[H_RECFORM] = 2ull;
+        }
+    }
+    // move region j's tail rows (rows at or beyond V) into the holes
+    const int j = (int)blockIdx.x % kRegions, slice = (int)blockIdx.x / kRegions, nslices = max(1, c.nblocks / kRegions);
+    const u32 tsj = (u32)__builtin_amdgcn_readlane((int)t.ts, j), tlj = (u32)__builtin_amdgcn_readlane((int)t.tl, j);
+    float* const v = c.verts;
+    for (u32 r0 = (u32)slice * kBlock; r0 < tlj; r0 += (u32)nslices * kBlock) {   // (block-uniform trip count)
+        const u32 r = r0 + (u32)tid;
+        const u32 src = tsj + min(r, tlj - 1u);
+        const u32 dst = tail_remap(src, t, lay_first);
+        if (r < tlj && (int64_t)src < c.capv && (int64_t)dst < c.capv) {
+            const float x = v[(size_t)src * 3], y = v[(size_t)src * 3 + 1], z = v[(size_t)src * 3 + 2];
+            v[(size_t)dst * 3] = x;
+            v[(size_t)dst * 3 + 1] = y;
+            v[(size_t)dst * 3 + 2] = z;
+        }
+    }
+}
+
 // A stack of items (a batch of grids) has one cursor block and 32 scratch regions per item: the launch's compaction
 // blocks are split evenly over the items (c.nblocks = nitems * slices * 32) and an item's vertices land behind those of
 // the items before it; the totals and per-item offsets of a stack are written by k_stack_finish, not here.
@@ -568,6 +748,7 @@ __device__ inline void compact_block(const CompactArgs& c, u64* __restrict__ hdr
             //  can have the faces and the compaction run again into larger ones, p3d_mc_slab.part = 6, without streaming the
             //  field a second time; the call's cursor block goes back to the stream's ring)
             if (lane < kRegions && c.nitems <= 1 && c.cursors != hdr + H_CURSORS) hdr[H_CURSORS + lane * kCursorStride] = cur;
+            if (lane < kRegions && c.nitems <= 1) mb_put_region(mb, lane, cur);   // (the adapter lays the next call's regions out from them)
             if (lane == kRegions - 1) {
                 hdr[H_V] = inc;
                 hdr[H_FLAGS] = flags;
@@ -737,7 +918,8 @@ __global__ void __launch_bounds__(kBlock) k_face_count_walk(const u64* __restric
                                                             u32* __restrict__ tile_tris, CompactArgs cp, u64* __restrict__ hdr) {
     if ((int)blockIdx.x < cp.nblocks) {  // the launch's first blocks move vertices (uniform per block)
         __shared__ u64 s_cb[kCompactSmemWords];
-        compact_block(cp, hdr, nullptr, 0, s_cb);
+        if (cp.layout) layout_move_block(cp, hdr);
+        else compact_block(cp, hdr, nullptr, 0, s_cb);
         return;
     }
     __shared__ u32 s_part[PB][4];
@@ -1013,7 +1195,8 @@ __device__ inline u32 row_nibble(u32 lo, u32 hi) {   // nibble N of the 64-bit t
     else return (hi >> (4 * (N - 8))) & 15u;
 }
 
-template <int NHALO>
+template <int NHALO, bool LAYOUT>   // LAYOUT: rec[].x is a row of the region layout (FaceArgs::xlate == 3) -- its own instantiation,
+                                    // so that the tables it carries do not cost the other forms a wave per SIMD
 __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, const uint2* __restrict__ rec, Dims d,
                                                    FaceArgs a, CompactArgs cp, u64* __restrict__ hdr,
                                                    int32_t* __restrict__ faces, int64_t cap_faces) {
@@ -1028,8 +1211,10 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
                                                          // the batch's unit markers (read before the ids are written), and the
                                                          // launch's compaction blocks borrow a corner as their scratch
     __shared__ u32 s_tmp[4];
+    __shared__ u32 s_strad[4];                           // layout form: a wave staged a unit whose ids are translated one by one
     if ((int)blockIdx.x < cp.nblocks) {  // the launch's first blocks move the vertices (uniform per block)
-        compact_block(cp, hdr, a.mb, a.seq, (u64*)&s_ids[0][0][0]);
+        if (cp.layout) layout_report_block(cp, hdr, a.mb, a.seq, (u64*)&s_ids[0][0][0]);
+        else compact_block(cp, hdr, a.mb, a.seq, (u64*)&s_ids[0][0][0]);
         return;
     }
 #if P3D_FACES_STAMP
@@ -1057,7 +1242,7 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     // of the prologue (512^3 noise: 67.6 -> 68.1 us over three runs each), so only launches that expect few triangles per
     // tile take it.
     if (a.sparse && a.tile_tris[b] == 0u) return;
-    const bool XLATE = a.xlate == 1 || (a.xlate == 2 && hdr[H_RECFORM] != 0ull);
+    const bool XLATE = !LAYOUT && (a.xlate == 1 || (a.xlate == 2 && hdr[H_RECFORM] == 1ull));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 x32 = fd_div(b, a.div_tpp);
     const int64_t x = x32;
@@ -1088,6 +1273,7 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
         mp = (lane < kRegions && XLATE) ? curp : mp;
         mp = (lane > 32 && lane < 37) ? a.wave_off + (size_t)b * 4 + (lane - 33) : mp;
         mp = (lane == 37 && a.chunk_pre) ? a.chunk_pre + mychunk32 : mp;
+        mp = (lane == 38 && LAYOUT) ? (const u32*)(hdr + H_V) : mp;   // (layout form: V, left there by the counting launch)
     }
     const int64_t p = tile * kBlock + tid;
     const int64_t y = fd_div((u32)p, a.div_ncz);   // (p < 2^31: check_dims)
@@ -1196,6 +1382,26 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     auto dense = [&](u32 v) -> u32 {
         return XLATE ? (v & 0x3ffffffu) + (u32)__builtin_amdgcn_ds_bpermute((int)(((v >> 26) & (kRegions - 1)) << 2), (int)pref) : v;
     };
+    // Layout form: a staged unit's first id is a ROW, final unless it lies at or beyond V (one of the few rows the counting
+    // launch moved into the holes the slack left).  A wave looks at the rows it stages; only if one of them can reach V does
+    // it fetch the tail tables (five loads, L2-resident) and translate -- per unit where the unit's run of ids lands in one
+    // hole, else the unit is marked and its ids are translated one by one in the cell batches (s_strad: any wave of the block).
+    const u32 layV = LAYOUT ? (u32)__builtin_amdgcn_readlane((int)misc, 38) : 0u;
+    u32 strad = 0;
+    bool wave_tail = false;
+    TailTables tt{};
+    u32 lay_first = 0, tail_end = 0;
+    if (LAYOUT) {   // (block-uniform)
+        bool mine_tail = false;
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            const bool hit0 = st_r0[q].x + 191u >= layV && st_r0[q].x + 191u >= st_r0[q].x;
+            const bool hit1 = st_r1[q].x + 191u >= layV && st_r1[q].x + 191u >= st_r1[q].x && !xhalo;
+            mine_tail = mine_tail || (st_in[q] && (hit0 || hit1));
+        }
+        wave_tail = __ballot(mine_tail) != 0ull;   // (wave-uniform)
+        if (wave_tail) tt = tail_tables_from_header(hdr, layV, &lay_first, &tail_end);
+    }
     if (a.chunk_pre) cs = lane == 37 && wave == 0 ? misc : 0u;
     u32* const E0 = s_e0;
     u32* const E1 = s_e1;
@@ -1203,8 +1409,13 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     for (int q = 0; q < NST; ++q) {   // (wave-uniform trip count: the translation shuffles across the wave's lanes)
         const int i = tid + q * kBlock;
         if (wave0 + q * kBlock >= nstage) continue;
-        const u32 base0 = dense(st_r0[q].x) + b0;
-        const u32 base1 = xhalo ? st_r1[q].x + bhalo : dense(st_r1[q].x) + b0;
+        u32 base0 = dense(st_r0[q].x) + b0;
+        u32 base1 = xhalo ? st_r1[q].x + bhalo : dense(st_r1[q].x) + b0;
+        if (wave_tail) {   // (wave-uniform; all lanes take part in the look-ups)
+            base0 = tail_unit(st_r0[q].x, tt, lay_first, tail_end, &strad);
+            const u32 t1 = tail_unit(st_r1[q].x, tt, lay_first, tail_end, &strad);
+            base1 = xhalo ? base1 : t1;
+        }
         // offsets of the unit's first x / y / z edge id (bytes 0 / 1 / 2): low half = the record's, high half = plus
         // the crossings of the low half (x crossings of plane x+1 belong to the next cell layer: not needed)
         const u64 w0 = st_w0[q], w1 = st_w1[q];
@@ -1229,6 +1440,8 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     {
         cs = (u32)__builtin_amdgcn_readlane((int)wave_prefix_sum(cs), 63);
         if (lane == 0) s_tmp[wave] = cs;
+        const u32 wave_strad = __ballot(strad != 0u) != 0ull ? 1u : 0u;
+        if (LAYOUT && lane == 0) s_strad[wave] = wave_strad;
     }
     FSTAMP(3);          // staged (LDS writes done)
     __syncthreads();  // the only block barrier: staging done (no store is in flight yet)
@@ -1236,6 +1449,9 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
 #if P3D_FACES_ABL == 1
     return;
 #endif
+    // layout form: does any cell of this tile read a marked unit?  (block-uniform; the tables again -- few tiles get here)
+    const bool per_id = LAYOUT && __builtin_amdgcn_readfirstlane((int)(s_strad[0] | s_strad[1] | s_strad[2] | s_strad[3])) != 0;
+    if (per_id && !wave_tail) tt = tail_tables_from_header(hdr, layV, &lay_first, &tail_end);
     // first face of this wave and the capacity, relative to it (a wave-tile emits at most 64 * 64 * 5 faces)
     const u32 wrun0 = (u32)__builtin_amdgcn_readfirstlane((int)(s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3])) +
                       (u32)__builtin_amdgcn_readlane((int)misc, 33 + wave);
@@ -1351,18 +1567,17 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
             const u32 id7 = z63 ? n7 : a7;
             const u32 id5 = z63 ? n5 : a5;
             const u32 id6 = z63 ? N3 : a6;
-            ids[0 * 64] = id0;
-            ids[1 * 64] = id1;
-            ids[2 * 64] = id2;
-            ids[3 * 64] = id3;
-            ids[4 * 64] = id4;
-            ids[5 * 64] = id5;
-            ids[6 * 64] = id6;
-            ids[7 * 64] = id7;
-            ids[8 * 64] = id8;
-            ids[9 * 64] = id9;
-            ids[10 * 64] = id10;
-            ids[11 * 64] = id11;
+            u32 idv[12] = {id0, id1, id2, id3, id4, id5, id6, id7, id8, id9, id10, id11};
+            if (per_id) {   // (block-uniform, rare: ids of marked units carry kTailMark and are rows of the layout)
+#pragma unroll
+                for (int e = 0; e < 12; ++e) {
+                    const u32 row = idv[e] & ~kTailMark;
+                    const u32 moved = tail_remap(row, tt, lay_first);
+                    idv[e] = (idv[e] & kTailMark) ? (row >= layV ? moved : row) : idv[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 12; ++e) ids[e * 64] = idv[e];
 #if P3D_FACES_STAMP
             if (i0 == 0) FSTAMP(7);   // first batch: ids computed and written
 #endif
@@ -1696,7 +1911,7 @@ int free_ring(const std::shared_ptr<CursorRing>& r, bool stream_alive) {
 // next sequence number, its kernels publish into slot seq % kMbSlots (mb_publish_*), and p3d_mc_read_counts polls that
 // slot.  The workspace pointer keys the pending call.  Anything unexpected (no pinned memory, slot recycled by 64
 // newer calls, time-out) falls back to the copy + synchronise path, which reads the same totals from the header.
-constexpr int kMbSlots = 64, kMbSlotWords = 8;
+constexpr int kMbSlots = 64, kMbSlotWords = 64;   // (a slot: 5 words of totals + 32 region totals at words 8..39)
 struct Mailbox {
     u64* host = nullptr;  // also valid as device pointer (hipHostMallocMapped, unified addressing)
     u64* dev = nullptr;
@@ -1750,7 +1965,7 @@ u64* mailbox_open(const void* ws, u64* seq_out) {
 }
 
 // polls the slot of the pending call on `ws`; false = not pending / recycled / timed out (use the copy path)
-bool mailbox_wait(const void* ws, u64* nv, u64* nf, u64* flags) {
+bool mailbox_wait(const void* ws, u64* nv, u64* nf, u64* flags, int64_t* regions = nullptr) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
     u64 seq = 0;
@@ -1779,8 +1994,11 @@ bool mailbox_wait(const void* ws, u64* nv, u64* nf, u64* flags) {
     // check above and these loads -- re-check the two sequence words after the payload
     const u64 v1 = __atomic_load_n(&slot[1], __ATOMIC_ACQUIRE), v2 = __atomic_load_n(&slot[2], __ATOMIC_ACQUIRE);
     const u64 v4 = __atomic_load_n(&slot[4], __ATOMIC_ACQUIRE);
+    int64_t reg[kRegions];
+    for (int r = 0; r < kRegions; ++r) reg[r] = (int64_t)__atomic_load_n(&slot[8 + r], __ATOMIC_ACQUIRE);
     if (__atomic_load_n(&slot[0], __ATOMIC_ACQUIRE) != seq || __atomic_load_n(&slot[3], __ATOMIC_ACQUIRE) != seq)
         return false;
+    if (regions) memcpy(regions, reg, sizeof(reg));
     *nv = v1;
     *flags = v2;
     *nf = v4;
@@ -1812,10 +2030,15 @@ void launch_faces(const Dims& d, const Ws& w, const u64* bits, const uint2* rec,
     //  field has 1270 per tile, a sphere 19)
     const int sparse_knob = tuning().faces_sparse;   // (P3D_FACES_SPARSE: -1 the rule, 0 never, 1 always -- dev A/B, tests)
     a.sparse = sparse_knob >= 0 ? sparse_knob : (faces_here && capf < (int64_t)w.nb_f * 128 ? 1 : 0);
-    if (d.ncz <= 32)
-        hipLaunchKernelGGL(k_faces<32>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
+    if (a.xlate == 3) {
+        if (d.ncz <= 32)
+            hipLaunchKernelGGL((k_faces<32, true>), fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
+        else
+            hipLaunchKernelGGL((k_faces<256, true>), fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
+    } else if (d.ncz <= 32)
+        hipLaunchKernelGGL((k_faces<32, false>), fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
     else
-        hipLaunchKernelGGL(k_faces<256>, fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
+        hipLaunchKernelGGL((k_faces<256, false>), fgrid, dim3(kBlock), 0, st, bits, rec, d, a, cp, hdr, faces, capf);
 }
 
 template <typename T>
@@ -1867,7 +2090,8 @@ int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3
 
 template <typename T>
 int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xform& t, const p3d_mc_slab* slab,
-              char* ws, float* verts, int64_t capv, int32_t* faces, int64_t capf, int64_t* keys, hipStream_t st) {
+              char* ws, float* verts, int64_t capv, int32_t* faces, int64_t capf, int64_t* keys, hipStream_t st,
+              bool layout_form = false) {
     const int halo = slab ? slab->halo_last_plane : 0;
     u64* bits = (u64*)(ws + w.bits);
     uint2* rec = (uint2*)(ws + w.rec);
@@ -1887,7 +2111,8 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
     }
     if (w.nb_f > 0 && capf > 0) {
         StageTimer tm(ST_EMIT_FACES, st);
-        const FaceArgs a{2, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
+        // (faces alone behind a call with a region layout: rows, translated with the tail tables the header still holds)
+        const FaceArgs a{layout_form ? 3 : 2, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
                          slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0,
                          (slab && slab->rank_counts_stride > 0) ? slab->rank_counts_stride : 1, w.tpp, w.xw, (int)w.cpi,
                          (const u32*)(ws + w.chunk_sum), nullptr, (const u32*)(ws + w.wave_off),
@@ -1904,7 +2129,10 @@ template <typename T, int NC, int RY>
 void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xform& t, int64_t x_origin, u64* bits,
                   uint2* rec, u64* cursors, u64* zero_next, float* scratch, u32 region_rows, u32 store_rows, int x_lo,
                   int x_hi,
-                  hipEvent_t ev0, hipEvent_t ev1, hipStream_t st, const u64* region_first_row, int cz_base = 0, int cz_count = -1) {
+                  hipEvent_t ev0, hipEvent_t ev1, hipStream_t st, const u64* region_first_row, const RegionLayout* layp,
+                  u64* lay_out, int cz_base = 0, int cz_count = -1) {
+    RegionLayout lay{};
+    if (layp) lay = *layp;
     FusedGeom g;
     g.x_lo = x_lo;
     g.x_hi = x_hi;
@@ -1969,11 +2197,11 @@ void launch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xf
     g_counters[0].fetch_add(1, std::memory_order_relaxed);
     // (the timing events, if any, ride on the dispatch packet itself: no extra barrier packets around the kernel)
     if (ev0 || ev1)   // (rows split over two launches: the first carries the start event, the second the stop event)
-        hipExtLaunchKernelGGL((k_fused<T, NC, RY>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, ev0, ev1, 0, grid, thresh,
+        hipExtLaunchKernelGGL((k_fused<T, NC, RY>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, ev0, ev1, 0, lay, lay_out, grid, thresh,
                               thresh16, d, g, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
                               store_rows, region_first_row);
     else
-        hipLaunchKernelGGL((k_fused<T, NC, RY>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, grid, thresh, thresh16, d, g,
+        hipLaunchKernelGGL((k_fused<T, NC, RY>), dim3((u32)nblocks), dim3(kFusedBlock), 0, st, lay, lay_out, grid, thresh, thresh16, d, g,
                            halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows, store_rows, region_first_row);
 }
 
@@ -1981,7 +2209,8 @@ template <typename T>
 void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const Xform& t, int64_t x_origin, u64* bits,
                     uint2* rec, u64* cursors, u64* zero_next, float* scratch, u32 region_rows, u32 store_rows, int x_lo,
                   int x_hi,
-                    hipEvent_t ev0, hipEvent_t ev1, hipStream_t st, const u64* region_first_row = nullptr) {
+                    hipEvent_t ev0, hipEvent_t ev1, hipStream_t st, const u64* region_first_row = nullptr,
+                    const RegionLayout* layp = nullptr, u64* lay_out = nullptr) {
     // tile geometries (32 unit words per wave-plane unless noted): long rows (8 chunks x 3 rows per wave), rows of 3-4
     // chunks (rz <= 256: 4 chunks x 6 rows -- the 8-chunk tile would be half empty -- or, for a single small grid,
     // 16-unit tiles of 4 chunks x 3 rows), short rows (2 chunks x 15 rows).
@@ -1992,14 +2221,14 @@ void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const 
         // full (513 x 511 x 517: 169 -> 155 us; with 3..4 chunks left over the split measured no gain)
         const int full = (int)d.ncz - rem;
         launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                     store_rows, x_lo, x_hi, ev0, nullptr, st, region_first_row, 0, full);
+                                     store_rows, x_lo, x_hi, ev0, nullptr, st, region_first_row, layp, lay_out, 0, full);
         launch_fused<T, 2, 15>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                      store_rows, x_lo, x_hi, nullptr, ev1, st, region_first_row, full, rem);
+                                      store_rows, x_lo, x_hi, nullptr, ev1, st, region_first_row, layp, lay_out, full, rem);
         return;
     }
     if (d.ncz >= 5)
         launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                    store_rows, x_lo, x_hi, ev0, ev1, st, region_first_row);
+                                    store_rows, x_lo, x_hi, ev0, ev1, st, region_first_row, layp, lay_out);
     else if (d.ncz >= 3 &&
              // (only when 8-plane slabs of the wider-in-y tile still give the chip enough blocks: a single small grid is
              //  better off with more, half-empty tiles than with 2-plane slabs)
@@ -2008,18 +2237,18 @@ void dispatch_fused(const T* grid, const Dims& d, float thresh, int halo, const 
         //  Perlin stacks -- a full batch of 64 and a nearly empty one --, one of 24 units ~64: 32 x 256^3 fp16 342 -> 328 us,
         //  fp32 556 -> 535 us)
         launch_fused<T, 4, 6>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                    store_rows, x_lo, x_hi, ev0, ev1, st, region_first_row);
+                                    store_rows, x_lo, x_hi, ev0, ev1, st, region_first_row, layp, lay_out);
     else if (d.ncz >= 3 && tuning().small16)
         // a single small grid: 16-unit tiles (4 chunks x 3 rows + halo row) -- twice the waves of the 8-chunk tile, none
         // of them half empty
         launch_fused<T, 4, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                     store_rows, x_lo, x_hi, ev0, ev1, st, region_first_row);
+                                     store_rows, x_lo, x_hi, ev0, ev1, st, region_first_row, layp, lay_out);
     else if (d.ncz >= 3)
         launch_fused<T, 8, 3>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                    store_rows, x_lo, x_hi, ev0, ev1, st, region_first_row);
+                                    store_rows, x_lo, x_hi, ev0, ev1, st, region_first_row, layp, lay_out);
     else
         launch_fused<T, 2, 15>(grid, d, thresh, halo, t, x_origin, bits, rec, cursors, zero_next, scratch, region_rows,
-                                      store_rows, x_lo, x_hi, ev0, ev1, st, region_first_row);
+                                      store_rows, x_lo, x_hi, ev0, ev1, st, region_first_row, layp, lay_out);
 }
 
 Xform make_xform(const Dims& d, const float lower[3], const float upper[3], const int64_t full_res[3]) {
@@ -2099,6 +2328,19 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     // parts (p3d_mc_slab.part): 0 everything; 1 planes [0, split) only; 2 planes [split, rx) + finalize;
     // 3 planes [split, rx) + early header, no finalize; 4 face count (+ first slices of the vertex copy), totals to
     // the host; 5 faces (+ the rest of the vertex copy); 6 faces + the WHOLE vertex copy (part 4 was given no vertex buffer)
+    // a predicted layout of the 32 regions inside the caller's vertex buffer (p3d_mc_slab.region_first_rows: whole-grid calls)
+    RegionLayout lay_v{};
+    const RegionLayout* lay = nullptr;
+    if (slab && slab->region_first_rows) {
+        if (part != 0 || halo || !verts || capv <= 0)
+            return fail(P3D_EINVAL, "region_first_rows: whole-grid calls (part 0, no halo plane) with a vertex buffer only%s");
+        for (int r = 0; r <= kRegions; ++r) lay_v.first[r] = slab->region_first_rows[r];
+        bool ok = lay_v.first[0] == 0u && (int64_t)lay_v.first[kRegions] <= capv && lay_v.first[kRegions] < 0x7fffff00u;
+        for (int r = 0; r < kRegions; ++r) ok = ok && lay_v.first[r] < lay_v.first[r + 1];
+        if (!ok) return fail(P3D_EINVAL, "region_first_rows must be 33 strictly ascending rows from 0 to at most cap_vertices%s");
+        lay_v.on = 1u;
+        lay = &lay_v;
+    }
     int x_lo = 0, x_hi = (int)d.rx;
     if (part == 1) x_hi = (int)slab->split_plane;
     if (part == 2 || part == 3) x_lo = (int)slab->split_plane;
@@ -2142,8 +2384,9 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         if (timed) g_ev_used[stage] = true;
         if (new_block && part != 1) g_ev_used[ST_FUSED_INTERIOR] = false;
         const int64_t xo = slab ? slab->x_origin : 0;
-        dispatch_fused<T>(grid, d, thresh, halo, t, xo, bits, rec, cursors, zero_next, scratch, region_rows, store_rows, x_lo, x_hi,
-                          timed ? g_ev[stage][0] : nullptr, timed ? g_ev[stage][1] : nullptr, st);
+        dispatch_fused<T>(grid, d, thresh, halo, t, xo, bits, rec, cursors, zero_next, lay ? verts : scratch, region_rows, store_rows,
+                          x_lo, x_hi, timed ? g_ev[stage][0] : nullptr, timed ? g_ev[stage][1] : nullptr, st, nullptr, lay,
+                          lay ? hdr + H_LAYOUT : nullptr);
         // (a launch that was refused never ran: the ring stays where it was)
         HIP_TRY(hipGetLastError());
         const bool holds = held && lease.ring && part == 1;   // the parts that continue the streaming find the block through the table
@@ -2175,6 +2418,27 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     // with a halo plane (its records arrive later: the faces are then written by p3d_mc_emit), the launch consists of
     // those first blocks only.
     const bool faces_here = w.nb_f > 0 && capf > 0 && (!halo || part >= 5);
+    if (lay) {
+        // Region-layout mode: the vertices are where they stay (but for the rows at or beyond V); the counting launch's 32
+        // riding blocks make V, the flags and the tail tables and move those rows; the face launch's one extra block reports.
+        u64 seq_l = 0;
+        u64* mb_l = mailbox_open(ws, &seq_l);
+        if (w.nchunks > 0 || true) {
+            StageTimer tm(ST_FACES_COUNT, st);
+            CompactArgs cpe{nullptr, verts, capv, 0, region_rows, kRegions, 0, 1, 0, csum, (int)w.nchunks, cursors, id_limit, 1, nullptr};
+            cpe.layout = 1;
+            launch_count_walk(dim3((u32)(w.nchunks + cpe.nblocks)), st, bits, d, w, csum, woff, (u32*)(ws + w.tile_tris), cpe, hdr);
+            if (cpre) hipLaunchKernelGGL(k_chunk_prefix, dim3(1), dim3(1024), 0, st, csum, (int)w.nchunks, cpre);
+        }
+        const FaceArgs a{3, 0, 0, 0, nullptr, 0, 1, w.tpp, w.xw, (int)w.cpi, csum, cpre, woff, (const u32*)(ws + w.tile_tris),
+                         cursors, mb_l, seq_l};
+        CompactArgs cp{nullptr, verts, capv, 0, region_rows, 1, 0, 1, 1, csum, (int)w.nchunks, cursors, id_limit, 1, nullptr};
+        cp.layout = 1;
+        StageTimer tm(ST_EMIT_FACES, st);
+        launch_faces(d, w, bits, rec, a, cp, hdr, faces, capf, faces_here, st);
+        HIP_TRY(hipGetLastError());
+        return P3D_OK;
+    }
     u64 seq = 0;
     // (p3d_mc_slab.defer_totals: part 4 reports nothing, the part 5 behind it reports V and F from its first block)
     const bool defer = slab && slab->defer_totals != 0 && (part == 4 || part == 5);
@@ -2298,6 +2562,7 @@ struct Extraction {
     const float* verts4 = nullptr;   // the vertex buffer part 4 began to fill (null: it copied nothing)
     int64_t capv4 = 0;
     HeldBlock held;                  // part 1's cursor block, for the parts that continue the streaming
+    bool layout = false;             // the extraction was a whole-grid call with a predicted region layout (rec[] holds rows)
     uint64_t last_use = 0;
 };
 constexpr size_t kMaxExtractions = 1024;
@@ -2315,6 +2580,7 @@ struct ProtoCall {   // what one call presents
     int64_t scratch_rows;
     const float* verts;
     int64_t capv;
+    bool layout = false;
 };
 
 int proto_fail(const char* what, int last_phase) {
@@ -2373,6 +2639,7 @@ int proto_check(const ProtoCall& c, Extraction* out) {
             break;
         case 6:
             if (last != PH_COUNTED && last != PH_DONE) return proto_fail("part 6 needs part 4, or a finished extraction, before it", last);
+            if (e.layout) return proto_fail("part 6 copies out of a scratch buffer: the extraction before it had none (region layout)", last);
             if (!same_scratch) return proto_fail("part 6 must be given the scratch buffer the field was streamed into", last);
             break;
         case -2:
@@ -2387,6 +2654,7 @@ int proto_check(const ProtoCall& c, Extraction* out) {
         e.stream = c.stream;
         e.rx = c.rx; e.ry = c.ry; e.rz = c.rz; e.dtype = c.dtype; e.split = c.split;
         e.scratch = c.scratch; e.scratch_rows = c.scratch_rows;
+        e.layout = c.layout;
     }
     switch (c.part) {
         case 0: case 2: case 5: case 6: e.phase = PH_DONE; break;
@@ -2487,16 +2755,27 @@ int p3d_mc_count_scan(const void* grid, int dtype, int64_t rx, int64_t ry, int64
 
 int p3d_mc_read_counts(const void* ws, int64_t* num_vertices, int64_t* num_faces, int32_t* scratch_overflow,
                        void* stream) {
+    return p3d_mc_read_counts_ex(ws, num_vertices, num_faces, scratch_overflow, nullptr, stream);
+}
+
+int p3d_mc_read_counts_ex(const void* ws, int64_t* num_vertices, int64_t* num_faces, int32_t* scratch_overflow,
+                          int64_t* region_totals, void* stream) {
     if (!ws || !num_vertices || !num_faces) return fail(P3D_EINVAL, "null pointer%s");
     u64 h[3] = {0, 0, 0};
     hipStream_t st = (hipStream_t)stream;
-    if (!mailbox_wait(ws, &h[H_V], &h[H_T], &h[H_FLAGS])) {
-        HIP_TRY(hipMemcpyAsync(h, ws, sizeof(h), hipMemcpyDeviceToHost, st));
+    if (!mailbox_wait(ws, &h[H_V], &h[H_T], &h[H_FLAGS], region_totals)) {
+        // (no mailbox: the header -- totals, and the region totals the finishing block copies to the header's cursor lines)
+        static_assert(H_CURSORS + kRegions * kCursorStride <= kHdrBytes / 8, "header");
+        std::vector<u64> hdr_copy(H_CURSORS + (size_t)kRegions * kCursorStride);
+        HIP_TRY(hipMemcpyAsync(hdr_copy.data(), ws, hdr_copy.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        for (int i = 0; i < 3; ++i) h[i] = hdr_copy[i];
+        if (region_totals)
+            for (int r = 0; r < kRegions; ++r) region_totals[r] = (int64_t)hdr_copy[H_CURSORS + (size_t)r * kCursorStride];
     }
     *num_vertices = (int64_t)h[H_V];
     *num_faces = (int64_t)h[H_T];
-    if (scratch_overflow) *scratch_overflow = (int32_t)(h[H_FLAGS] & 3ull);
+    if (scratch_overflow) *scratch_overflow = (int32_t)(h[H_FLAGS] & 7ull);
     // (test hook: P3D_TEST_INDEX_LIMIT pretends the int32 limit is smaller, to reach the callers' handling of it)
     const u64 index_limit = (u64)std::max(1, tuning().test_index_limit);
     if (h[H_V] > index_limit || h[H_T] > index_limit)
@@ -2523,16 +2802,26 @@ int p3d_mc_emit(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz,
     // pass into the exactly sized buffers.  Ids handed out before must survive in every other case -- a slab (its first
     // plane's records may already be with the neighbour), vertices or faces alone, the keys of the parity tests, ids
     // renumbered by p3d_mc_count_scan -- and there the gather emitter writes by id.
+    if (next.layout && !(cap_vertices > 0 && cap_faces > 0) && cap_vertices > 0)
+        return fail(P3D_EINVAL, "behind a call with a region layout p3d_mc_emit takes both buffers (it streams the field again) or "
+                                "faces alone%s");
+    if (next.layout && (slab || vertex_keys))
+        return fail(P3D_EINVAL, "behind a call with a region layout p3d_mc_emit takes neither a slab nor vertex_keys%s");
     if (!slab && !vertex_keys && cap_vertices > 0 && cap_faces > 0 && next.phase != PH_COUNT_SCAN) {
-        if (dtype == P3D_F32)
-            return emit_stream_impl((const float*)grid, d, w, thresh, t, (char*)ws, vertices, cap_vertices, faces, cap_faces, st);
-        return emit_stream_impl((const __half*)grid, d, w, thresh, t, (char*)ws, vertices, cap_vertices, faces, cap_faces, st);
+        const int rc = dtype == P3D_F32
+                           ? emit_stream_impl((const float*)grid, d, w, thresh, t, (char*)ws, vertices, cap_vertices, faces, cap_faces, st)
+                           : emit_stream_impl((const __half*)grid, d, w, thresh, t, (char*)ws, vertices, cap_vertices, faces, cap_faces, st);
+        if (rc == P3D_OK && next.layout) {   // (the records are in region form again: a later faces-only emit reads them so)
+            next.layout = false;
+            proto_commit(ws, next);
+        }
+        return rc;
     }
     if (dtype == P3D_F32)
         return emit_impl((const float*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices, faces,
-                         cap_faces, vertex_keys, st);
+                         cap_faces, vertex_keys, st, next.layout);
     return emit_impl((const __half*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices, faces,
-                     cap_faces, vertex_keys, st);
+                     cap_faces, vertex_keys, st, next.layout);
 }
 
 int p3d_mc_extract_fused(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz, float thresh,
@@ -2543,8 +2832,13 @@ int p3d_mc_extract_fused(const void* grid, int dtype, int64_t rx, int64_t ry, in
     if (!grid || !ws || !lower || !upper) return fail(P3D_EINVAL, "null pointer%s");
     if ((cap_vertices > 0 && !vertices) || (cap_faces > 0 && !faces)) return fail(P3D_EINVAL, "null output%s");
     if (cap_vertices < 0 || cap_faces < 0 || scratch_rows < 0) return fail(P3D_EINVAL, "negative capacity%s");
-    if (cap_vertices > 0 && (!vertex_scratch || scratch_rows < kRegions))
-        return fail(P3D_EINVAL, "vertex output needs a scratch buffer of at least 32 rows%s");
+    const bool has_layout = slab && slab->region_first_rows;
+    if (has_layout) {   // (the regions live in `vertices`: a scratch buffer, if given, is not used)
+        vertex_scratch = nullptr;
+        scratch_rows = 0;
+    }
+    if (cap_vertices > 0 && !has_layout && (!vertex_scratch || scratch_rows < kRegions))
+        return fail(P3D_EINVAL, "vertex output needs a scratch buffer of at least 32 rows (or a region layout)%s");
     if (int rc = check_dims(rx, ry, rz)) return rc;
     if (slab && (slab->part < 0 || slab->part > 6)) return fail(P3D_EINVAL, "bad slab part%s");
     if (slab && slab->rank_counts && (slab->rank < 0 || slab->rank >= 64))
@@ -2560,7 +2854,7 @@ int p3d_mc_extract_fused(const void* grid, int dtype, int64_t rx, int64_t ry, in
     if (dtype != P3D_F32 && dtype != P3D_F16) return fail(P3D_EINVAL, "unknown dtype%s");
     Extraction next;
     if (int rc = proto_check(ProtoCall{ws, slab ? slab->part : 0, st, rx, ry, rz, slab ? slab->split_plane : 0, dtype,
-                                       vertex_scratch, vertex_scratch ? scratch_rows : 0, vertices, cap_vertices}, &next))
+                                       vertex_scratch, vertex_scratch ? scratch_rows : 0, vertices, cap_vertices, has_layout}, &next))
         return rc;
     const int rc = dtype == P3D_F32
                        ? fused_impl((const float*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices, vertex_scratch,

@@ -33,6 +33,30 @@ def vertex_keys_from_workspace(ws: np.ndarray, shape, nv: int, layout: dict, hal
         prefix = hdr[32 + 32 * 16:32 + 32 * 16 + 32].astype(np.int64)  # H_PREFIX
         region = np.minimum(base >> 26, 31)
         base = (base & 0x3FFFFFF) + prefix[region]
+    if int(hdr[3]) == 2:  # region-layout form: rec[].x is a ROW; rows at or beyond V were moved into the holes below V
+        H_LAYOUT, H_TS, H_TP, H_HS, H_HP = 600, 640, 672, 704, 736
+        assert int(hdr[0]) == nv
+        first = hdr[H_LAYOUT:H_LAYOUT + 33].astype(np.int64)
+        ts, tp = hdr[H_TS:H_TS + 32].astype(np.int64), hdr[H_TP:H_TP + 32].astype(np.int64)
+        hs, hp = hdr[H_HS:H_HS + 32].astype(np.int64), hdr[H_HP:H_HP + 33].astype(np.int64)
+        counts = hdr[32:32 + 32 * 16:16].astype(np.int64)
+        # the tables against their definition (p3d_mc.hip: tail_tables)
+        end = first[:32] + np.minimum(counts, first[1:] - first[:32])
+        assert (ts == np.maximum(first[:32], nv)).all() and (hs == np.minimum(end, nv)).all()
+        tl, hl = np.maximum(end, nv) - ts, np.minimum(first[1:], nv) - hs
+        assert (tp == np.cumsum(tl) - tl).all() and (hp[:32] == np.cumsum(hl) - hl).all() and hp[32] == hl.sum() == tl.sum()
+
+        def to_dense(row):   # ids of a unit, one by one (a unit's run may be split by the move)
+            out = row.copy()
+            m = row >= nv
+            r = row[m]
+            j = np.searchsorted(first[:32], r, side="right") - 1
+            kk = tp[j] + (r - ts[j])
+            i = np.searchsorted(hp[:32], kk, side="right") - 1
+            out[m] = hs[i] + (kk - hp[i])
+            return out
+    else:
+        to_dense = None
     offy = (rec[..., 1] & 0xFFFF).astype(np.int64)
     offz = (rec[..., 1] >> 16).astype(np.int64)
     for axis, (cr, off) in enumerate(((cx, None), (cy, offy), (cz, offz))):
@@ -41,6 +65,8 @@ def vertex_keys_from_workspace(ws: np.ndarray, shape, nv: int, layout: dict, hal
         vid = base[..., None] + rank + (0 if off is None else off[..., None])
         sel = cu
         v = vid[sel]
+        if to_dense is not None:
+            v = to_dense(v)
         k = lin.reshape(rx, ry, ncz, 64)[sel] * 3 + axis
         assert v.size == 0 or (v.min() >= 0 and v.max() < nv), (axis, v.min() if v.size else None, nv)
         assert (keys[v] == -1).all(), "vertex id assigned twice"
