@@ -97,10 +97,13 @@ constexpr int kHdrBytes = 8192;   // [0,256) totals/flags; [256,4352) the 32 cur
 enum { H_V = 0, H_T = 1, H_FLAGS = 2, H_RECFORM = 3 /* 1: rec[].x still region * 2^26 + slot; 2: rec[].x is a row of the
                                                          region layout, rows at or beyond V are remapped (H_TAIL_*) */,
        H_CURSORS = 32 /* u64 index */, H_PREFIX = 32 + 32 * 16,
-       H_LAYOUT = 600 /* [33] first row of every region (+ the end), copied there by the streaming kernel */,
-       H_TAIL_TS = 640 /* [32] first row at or beyond V of region r */, H_TAIL_TP = 672 /* [32] such rows in regions < r */,
-       H_TAIL_HS = 704 /* [32] first free row below V behind region r */, H_TAIL_HP = 736 /* [33] free rows behind regions < r */,
-       H_TAIL_TE = 776 /* [32] end of region r's rows at or beyond V (= ts_r when it has none) */ };
+       H_LAYOUT = 600 /* [34] first row of every region, of the spill area, and its end: copied there by the streaming kernel */,
+       // the 33 intervals of the layout (32 regions + the spill area), as the counting launch's riding block 0 leaves them:
+       H_LAY_OCC = 840 /* [33] rows interval i really holds */,
+       H_TAIL_TS = 640 /* [33] first row at or beyond V of interval i */, H_TAIL_TP = 680 /* [33] such rows in intervals < i */,
+       H_TAIL_HS = 720 /* [33] first free row below V behind interval i's rows */, H_TAIL_HP = 760 /* [34] free rows behind intervals < i */,
+       H_TAIL_TE = 800 /* [33] end of interval i's rows at or beyond V (= ts_i when it has none) */ };
+constexpr int kLayIv = 33;   // intervals of a region layout: the 32 regions and the spill area
 
 __host__ __device__ inline Dims make_dims(int64_t rx, int64_t ry, int64_t rz) {
     Dims d;
@@ -500,6 +503,7 @@ struct FaceArgs {
     u64 seq;
     FastDiv div_tpp = {1, 0, 0}, div_xper = {1, 0, 0}, div_ncz = {1, 0, 0};   // (filled in by launch_faces)
     int xw_shift = 0;                                                           // log2(xw)
+    const float* lay_verts = nullptr;   // layout form: the vertex buffer -- a moved row's first word holds the row it went to
     int sparse = 0;   // the caller expects few triangles per tile (launch_faces, from the face capacity): a block first asks
                       // for its tile's triangle count alone -- one scalar load -- and an empty tile leaves before any of the
                       // prologue's vector loads is issued
@@ -537,104 +541,65 @@ struct CompactArgs {
 };
 typedef float F4U __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access at 4-byte alignment
 typedef float F4A __attribute__((ext_vector_type(4)));
-// Region-layout mode (RegionLayout, fused_stream.inc).  Occupied rows: O = union of [first_r, first_r + n_r); V = sum n_r.
-// Rows of O at or beyond V ("tail": what the slack between the regions pushed out) move into the free rows below V
-// ("holes"), k-th tail row -> k-th hole, both in ascending order -- one interval of each kind per region:
-//     tail of region r  [ts_r, ts_r + tl_r) = [max(first_r, V), max(first_r + n_r, V))        tp_r = tail rows of regions < r
-//     hole behind r     [hs_r, hs_r + hl_r) = [min(first_r + n_r, V), min(first_(r+1), V))    hp_r = hole rows behind regions < r
-// (n_r clipped to the region's rows: a region that outgrew them sets flag 4 and the caller re-emits).  Every block works the
-// tables out for itself from the 32 cursors and the layout the streaming kernel left in the header; block 0 writes them
-// there for k_faces (and for tests/ws_keys.py); block j moves region j's tail rows.
+// Region-layout mode (RegionLayout, fused_stream.inc).  33 intervals: the 32 regions and the spill area.  Interval i holds
+// rows [first_i, first_i + occ_i): occ of a region = its fill mark if a wave-plane of it turned to the spill area, else
+// min(total, its rows); occ of the spill area = min(its cursor, its rows).  V = the sum of the 32 region totals (= the sum
+// of all occ when the spill area did not overflow).  Rows at or beyond V ("tail") move into the free rows below V ("holes"),
+// k-th tail row -> k-th hole, both in ascending order -- one interval of each kind per layout interval:
+//     tail of i      [ts_i, ts_i + tl_i) = [max(first_i, V), max(first_i + occ_i, V))        tp_i = tail rows of intervals < i
+//     hole behind i  [hs_i, hs_i + hl_i) = [min(first_i + occ_i, V), min(first_(i+1), V))    hp_i = hole rows behind intervals < i
+// Every riding block works the tables out for itself (lane i < 33 = interval i); block 0 writes them into the header for
+// k_faces (and for tests/ws_keys.py).
 struct TailTables {
-    u32 V, ts, tl, tp, hs, hl, hp;   // lane r < 32: region r's entries
+    u32 V, ts, tl, tp, hs, hl, hp;   // lane i < 33: interval i's entries
 };
-__device__ inline TailTables tail_tables(const u64* __restrict__ cursors, const u64* __restrict__ hdr_layout, u32* over_out) {
+__device__ inline TailTables tail_tables(const u64* __restrict__ cursors, const u64* __restrict__ hdr_layout, u32* over_out,
+                                         u32* occ_out) {
     const int lane = threadIdx.x & 63;
-    const bool mine = lane < kRegions;
+    const bool mine = lane < kLayIv, region = lane < kRegions;
     const u32 first = mine ? (u32)hdr_layout[lane] : 0u, next = mine ? (u32)hdr_layout[lane + 1] : 0u;
-    const u64 cur = mine ? cursors[lane * kCursorStride] : 0ull;
     const u32 rows = next - first;
-    const u32 n = (u32)min(cur, (u64)rows);   // rows the region really holds
-    if (over_out) *over_out = (__ballot(cur > (u64)rows) != 0ull) ? 1u : 0u;
-    u64 v64 = cur;   // V counts every vertex, stored or not (the caller sizes its re-emission from it)
+    const u64 cur = region ? cursors[lane * kCursorStride] : (lane == kRegions ? cursors[kSpillWord] : 0ull);
+    const u64 fill = region ? cursors[lane * kCursorStride + kFillWord] : 0ull;
+    const u32 occ = fill ? (u32)(fill - 1ull) : (u32)min(cur, (u64)rows);
+    if (occ_out) *occ_out = occ;
+    if (over_out) *over_out = (__ballot(lane == kRegions && cur > (u64)rows) != 0ull) ? 1u : 0u;   // the spill area overflowed
+    u64 v64 = region ? cur : 0ull;   // V counts every vertex, stored or not (the caller sizes its re-emission from it)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v64 += __shfl_xor(v64, o, 64);
     TailTables t;
     t.V = (u32)min(v64, (u64)0xffffffffull);
-    const u32 end = first + n;
+    const u32 end = first + occ;
     t.ts = max(first, t.V);
-    t.tl = max(end, t.V) - t.ts;
+    t.tl = mine ? max(end, t.V) - t.ts : 0u;
     t.hs = min(end, t.V);
     t.hl = mine ? min(next, t.V) - t.hs : 0u;
-    if (!mine) t.tl = 0u;
     t.tp = wave_prefix_sum(t.tl) - t.tl;
     t.hp = wave_prefix_sum(t.hl) - t.hl;
-    return t;
-}
-// dense row of a row at or beyond V: lane-held tables (lane r = region r), looked up with ds_bpermute (ALL lanes active).
-// *region receives the region the row lies in.
-__device__ inline u32 tail_remap(u32 row, const TailTables& t, u32 lay_first /* lane r <= 32: first_r, else ~0 */, u32* region = nullptr) {
-    // region of the row: the last r with first_r <= row (first_ is strictly ascending, first_0 = 0)
-    u32 j = 0;
-#pragma unroll
-    for (int h = 16; h >= 1; h >>= 1) {
-        const u32 f = (u32)__builtin_amdgcn_ds_bpermute((int)((j + h) << 2), (int)lay_first);
-        j = (f <= row) ? j + h : j;
-    }
-    if (region) *region = j;
-    const u32 tsj = (u32)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)t.ts);
-    const u32 tpj = (u32)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)t.tp);
-    const u32 k = tpj + (row - tsj);
-    // hole interval: the LAST i with hp_i <= k (hp_ is non-decreasing: empty intervals are stepped over)
-    u32 i = 0;
-#pragma unroll
-    for (int h = 16; h >= 1; h >>= 1) {
-        const u32 hpv = (u32)__builtin_amdgcn_ds_bpermute((int)((i + h) << 2), (int)t.hp);
-        i = (hpv <= k) ? i + h : i;
-    }
-    const u32 hsi = (u32)__builtin_amdgcn_ds_bpermute((int)(i << 2), (int)t.hs);
-    const u32 hpi = (u32)__builtin_amdgcn_ds_bpermute((int)(i << 2), (int)t.hp);
-    return hsi + (k - hpi);
-}
-// the tail tables as the counting launch's block 0 left them in the header (lane r < 32: region r); *tail_end: lane r = the
-// end of region r's rows at or beyond V
-__device__ inline TailTables tail_tables_from_header(const u64* __restrict__ hdr, u32 V, u32* lay_first, u32* tail_end) {
-    const int lane = threadIdx.x & 63;
-    const int r = lane & (kRegions - 1);
-    auto ld = [&](int idx) { return (u32)__hip_atomic_load(hdr + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-    TailTables t{};
-    t.V = V;
-    t.ts = ld(H_TAIL_TS + r);
-    t.tp = ld(H_TAIL_TP + r);
-    t.hs = ld(H_TAIL_HS + r);
-    t.hp = ld(H_TAIL_HP + r);
-    *tail_end = ld(H_TAIL_TE + r);
-    const u32 lf = ld(H_LAYOUT + min(lane, kRegions));
-    *lay_first = lane <= kRegions ? lf : 0xffffffffu;
-    if (lane >= kRegions) {   // (never selected: the searches stay below 32)
+    if (!mine) {   // (never selected: the searches stay below 33)
         t.ts = t.tp = t.hp = 0xffffffffu;
         t.hs = 0u;
     }
     return t;
 }
-constexpr u32 kTailMark = 0x80000000u;   // a staged base whose ids may straddle a cut of the remap: translated id by id
-// A staged unit's first id in layout form -> its dense first id, or -- the unit's run of at most 192 ids may cross V or the
-// end of a hole -- the row itself with kTailMark: its ids are then translated one by one.  ALL lanes must be active.
-__device__ inline u32 tail_unit(u32 row, const TailTables& t, u32 lay_first, u32 tail_end, u32* strad) {
-    const u32 V = t.V;
-    u32 j = 0;
-    const u32 r0 = tail_remap(row, t, lay_first, &j);
-    const u32 te = (u32)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)tail_end);
-    const u32 last = min(row + 191u, te - 1u);                    // the run cannot leave its region's rows
-    const u32 r1 = tail_remap(max(last, row), t, lay_first);
-    const bool fin = row + 191u < V || row + 191u < row;          // wholly below V (or garbage that wrapped: never used)
-    const bool crossV = !fin && row < V;
-    // inside ONE region's tail the rows' order numbers are consecutive, the map is strictly increasing: equal spans = a shift
-    const bool whole = !fin && !crossV && last >= row && (r1 - r0 == last - row);
-    const bool marked = !fin && !whole;
-    if (marked) *strad = 1u;
-    return fin ? row : (whole ? r0 : (row | kTailMark));
+// the LAST lane i < 33 with tab_i <= key (tab non-decreasing over the lanes 0..32, ~0 beyond): ds_bpermute, ALL lanes active
+__device__ inline u32 last_not_above(u32 tab, u32 key) {
+    u32 i = 0;
+#pragma unroll
+    for (int h = 32; h >= 1; h >>= 1) {
+        const u32 v = (u32)__builtin_amdgcn_ds_bpermute((int)(min(i + (u32)h, 63u) << 2), (int)tab);
+        i = (i + (u32)h < (u32)kLayIv && v <= key) ? i + (u32)h : i;
+    }
+    return i;
 }
+// k-th tail row's place below V
+__device__ inline u32 hole_of(u32 k, const TailTables& t) {
+    const u32 i = last_not_above(t.hp, k);   // (empty holes are stepped over by taking the LAST)
+    const u32 hsi = (u32)__builtin_amdgcn_ds_bpermute((int)(i << 2), (int)t.hs);
+    const u32 hpi = (u32)__builtin_amdgcn_ds_bpermute((int)(i << 2), (int)t.hp);
+    return hsi + (k - hpi);
+}
+constexpr u32 kTailMark = 0x80000000u;   // a staged base whose unit's ids may be moved rows: translated id by id (k_faces)
 // the face launch's one extra block in layout mode: F, and the report to the host (V and the flags were left in the header by
 // the counting launch's block 0; the 32 region totals travel with them: the adapter lays the next call out from them)
 __device__ inline void layout_report_block(const CompactArgs& c, u64* __restrict__ hdr, u64* mb, u64 seq, u64* smem) {
@@ -654,20 +619,20 @@ __device__ inline void layout_report_block(const CompactArgs& c, u64* __restrict
         mb_publish_v(mb, seq, hdr[H_V], hdr[H_FLAGS]);   // (a release store: the region totals of this wave's lanes go first)
     }
 }
-// the counting launch's riding blocks in layout mode: block 0 writes V, the flags and the tail tables; block j moves region
-// (j mod 32)'s rows at or beyond V into the holes
+// the counting launch's riding blocks in layout mode: block 0 writes V, the flags and the tail tables; all of them together
+// move the rows at or beyond V into the holes (thread <-> k-th tail row; few rows: the blocks are done long before the count)
 __device__ inline void layout_move_block(const CompactArgs& c, u64* __restrict__ hdr) {
     const int tid = threadIdx.x, lane = tid & 63;
-    u32 over = 0;
-    const TailTables t = tail_tables(c.cursors, hdr + H_LAYOUT, &over);   // (every wave of every block: 32 + 33 loads)
-    const u32 lay_first = lane <= kRegions ? (u32)hdr[H_LAYOUT + lane] : 0xffffffffu;
+    u32 over = 0, occ = 0;
+    const TailTables t = tail_tables(c.cursors, hdr + H_LAYOUT, &over, &occ);   // (every wave of every block: ~100 loads)
     if (blockIdx.x == 0 && tid < 64) {
-        if (lane < kRegions) {
+        if (lane < kLayIv) {
             hdr[H_TAIL_TS + lane] = t.ts;
             hdr[H_TAIL_TP + lane] = t.tp;
             hdr[H_TAIL_HS + lane] = t.hs;
             hdr[H_TAIL_HP + lane] = t.hp;
             hdr[H_TAIL_TE + lane] = t.ts + t.tl;
+            hdr[H_LAY_OCC + lane] = occ;
         }
         const u64 cur = lane < kRegions ? c.cursors[lane * kCursorStride] : 0ull;
         // (what a later p3d_mc_emit reads: the region totals and their prefix, as the scratch mode leaves them)
@@ -679,26 +644,30 @@ __device__ inline void layout_move_block(const CompactArgs& c, u64* __restrict__
             if (lane >= o) inc += tt;
         }
         if (lane < kRegions) hdr[H_PREFIX + lane] = inc - cur;
+        if (lane == kLayIv - 1) hdr[H_TAIL_HP + kLayIv] = t.hp + t.hl;
         if (lane == kRegions - 1) {
-            hdr[H_TAIL_HP + kRegions] = t.hp + t.hl;
             hdr[H_V] = inc;
             hdr[H_FLAGS] = (over ? 4ull : 0ull) | (inc > 0x7fffffffull ? 2ull : 0ull);
             hdr[H_RECFORM] = 2ull;
         }
     }
-    // move region j's tail rows (rows at or beyond V) into the holes
-    const int j = (int)blockIdx.x % kRegions, slice = (int)blockIdx.x / kRegions, nslices = max(1, c.nblocks / kRegions);
-    const u32 tsj = (u32)__builtin_amdgcn_readlane((int)t.ts, j), tlj = (u32)__builtin_amdgcn_readlane((int)t.tl, j);
+    // the k-th tail row (ascending) goes to the k-th free row below V
+    const u32 ntail = (u32)__builtin_amdgcn_readlane((int)(t.tp + t.tl), kLayIv - 1);
     float* const v = c.verts;
-    for (u32 r0 = (u32)slice * kBlock; r0 < tlj; r0 += (u32)nslices * kBlock) {   // (block-uniform trip count)
-        const u32 r = r0 + (u32)tid;
-        const u32 src = tsj + min(r, tlj - 1u);
-        const u32 dst = tail_remap(src, t, lay_first);
-        if (r < tlj && (int64_t)src < c.capv && (int64_t)dst < c.capv) {
+    const u32 stride = (u32)c.nblocks * kBlock;
+    for (u32 k0 = (u32)blockIdx.x * kBlock; k0 < ntail; k0 += stride) {   // (block-uniform trip count)
+        const u32 k = min(k0 + (u32)tid, ntail - 1u);
+        const u32 j = last_not_above(t.tp, k);   // (intervals without tail rows are stepped over by taking the LAST)
+        const u32 tsj = (u32)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)t.ts);
+        const u32 tpj = (u32)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)t.tp);
+        const u32 src = tsj + (k - tpj);
+        const u32 dst = hole_of(k, t);
+        if (k0 + (u32)tid < ntail && (int64_t)src < c.capv && (int64_t)dst < c.capv) {
             const float x = v[(size_t)src * 3], y = v[(size_t)src * 3 + 1], z = v[(size_t)src * 3 + 2];
             v[(size_t)dst * 3] = x;
             v[(size_t)dst * 3 + 1] = y;
             v[(size_t)dst * 3 + 2] = z;
+            v[(size_t)src * 3] = __uint_as_float(dst);   // where the row went: k_faces translates the ids of moved rows through it
         }
     }
 }
@@ -1274,6 +1243,7 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
         mp = (lane > 32 && lane < 37) ? a.wave_off + (size_t)b * 4 + (lane - 33) : mp;
         mp = (lane == 37 && a.chunk_pre) ? a.chunk_pre + mychunk32 : mp;
         mp = (lane == 38 && LAYOUT) ? (const u32*)(hdr + H_V) : mp;   // (layout form: V, left there by the counting launch)
+        mp = (lane == 39 && LAYOUT) ? (const u32*)(hdr + H_LAYOUT + kLayIv) : mp;   // (... and the end of the layout's rows)
     }
     const int64_t p = tile * kBlock + tid;
     const int64_t y = fd_div((u32)p, a.div_ncz);   // (p < 2^31: check_dims)
@@ -1382,26 +1352,13 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     auto dense = [&](u32 v) -> u32 {
         return XLATE ? (v & 0x3ffffffu) + (u32)__builtin_amdgcn_ds_bpermute((int)(((v >> 26) & (kRegions - 1)) << 2), (int)pref) : v;
     };
-    // Layout form: a staged unit's first id is a ROW, final unless it lies at or beyond V (one of the few rows the counting
-    // launch moved into the holes the slack left).  A wave looks at the rows it stages; only if one of them can reach V does
-    // it fetch the tail tables (five loads, L2-resident) and translate -- per unit where the unit's run of ids lands in one
-    // hole, else the unit is marked and its ids are translated one by one in the cell batches (s_strad: any wave of the block).
+    // Layout form: a staged unit's first id is a ROW, final unless the unit's run of at most 192 ids can reach V: such a unit
+    // is MARKED (bit 31 of its base) and its ids are translated one by one in the cell batches -- a row at or beyond V was
+    // moved by the counting launch's riding blocks, which left the row it went to in the old row's first word.  (Records of
+    // units without vertices hold whatever the memory held: only a row inside the layout can be a moved one.)
     const u32 layV = LAYOUT ? (u32)__builtin_amdgcn_readlane((int)misc, 38) : 0u;
+    const u32 layEnd = LAYOUT ? (u32)__builtin_amdgcn_readlane((int)misc, 39) : 0u;
     u32 strad = 0;
-    bool wave_tail = false;
-    TailTables tt{};
-    u32 lay_first = 0, tail_end = 0;
-    if (LAYOUT) {   // (block-uniform)
-        bool mine_tail = false;
-#pragma unroll
-        for (int q = 0; q < NST; ++q) {
-            const bool hit0 = st_r0[q].x + 191u >= layV && st_r0[q].x + 191u >= st_r0[q].x;
-            const bool hit1 = st_r1[q].x + 191u >= layV && st_r1[q].x + 191u >= st_r1[q].x && !xhalo;
-            mine_tail = mine_tail || (st_in[q] && (hit0 || hit1));
-        }
-        wave_tail = __ballot(mine_tail) != 0ull;   // (wave-uniform)
-        if (wave_tail) tt = tail_tables_from_header(hdr, layV, &lay_first, &tail_end);
-    }
     if (a.chunk_pre) cs = lane == 37 && wave == 0 ? misc : 0u;
     u32* const E0 = s_e0;
     u32* const E1 = s_e1;
@@ -1411,10 +1368,12 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
         if (wave0 + q * kBlock >= nstage) continue;
         u32 base0 = dense(st_r0[q].x) + b0;
         u32 base1 = xhalo ? st_r1[q].x + bhalo : dense(st_r1[q].x) + b0;
-        if (wave_tail) {   // (wave-uniform; all lanes take part in the look-ups)
-            base0 = tail_unit(st_r0[q].x, tt, lay_first, tail_end, &strad);
-            const u32 t1 = tail_unit(st_r1[q].x, tt, lay_first, tail_end, &strad);
-            base1 = xhalo ? base1 : t1;
+        if (LAYOUT) {
+            const bool m0 = st_in[q] && st_r0[q].x + 191u >= layV && st_r0[q].x < layEnd;
+            const bool m1 = st_in[q] && st_r1[q].x + 191u >= layV && st_r1[q].x < layEnd && !xhalo;
+            base0 = m0 ? (base0 | kTailMark) : base0;
+            base1 = m1 ? (base1 | kTailMark) : base1;
+            strad |= (m0 || m1) ? 1u : 0u;
         }
         // offsets of the unit's first x / y / z edge id (bytes 0 / 1 / 2): low half = the record's, high half = plus
         // the crossings of the low half (x crossings of plane x+1 belong to the next cell layer: not needed)
@@ -1451,7 +1410,6 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
 #endif
     // layout form: does any cell of this tile read a marked unit?  (block-uniform; the tables again -- few tiles get here)
     const bool per_id = LAYOUT && __builtin_amdgcn_readfirstlane((int)(s_strad[0] | s_strad[1] | s_strad[2] | s_strad[3])) != 0;
-    if (per_id && !wave_tail) tt = tail_tables_from_header(hdr, layV, &lay_first, &tail_end);
     // first face of this wave and the capacity, relative to it (a wave-tile emits at most 64 * 64 * 5 faces)
     const u32 wrun0 = (u32)__builtin_amdgcn_readfirstlane((int)(s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3])) +
                       (u32)__builtin_amdgcn_readlane((int)misc, 33 + wave);
@@ -1492,7 +1450,12 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
     FSTAMP(5);
     stamp[10] = na;
 #endif
-    {
+    // the cell batches, in two versions of the same text: the second translates the ids of marked units one by one
+    // (layout form, the few tiles that stage such a unit).  Two versions, not a branch inside the loop: a conditional
+    // region with LDS look-ups in the batch makes the compiler drain the batch's LDS reads at its borders -- the
+    // reads this loop issues together -- and cost every tile 40 % (k_faces 58 -> 82 us with four tiles on that path)
+    auto batches = [&](auto per_id_tag) {
+        constexpr bool PER_ID = decltype(per_id_tag)::value;
         for (u32 i0 = 0; i0 < na; i0 += 64) {
             // phase C (lane = cell slot i0 + lane).  Its unit: the units that start inside this batch drop a marker on
             // their first slot, a prefix max spreads it (slots in front of the first marker belong to the last unit that
@@ -1568,12 +1531,13 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
             const u32 id5 = z63 ? n5 : a5;
             const u32 id6 = z63 ? N3 : a6;
             u32 idv[12] = {id0, id1, id2, id3, id4, id5, id6, id7, id8, id9, id10, id11};
-            if (per_id) {   // (block-uniform, rare: ids of marked units carry kTailMark and are rows of the layout)
+            if constexpr (PER_ID) {   // (ids of marked units carry kTailMark and are rows of the layout)
 #pragma unroll
                 for (int e = 0; e < 12; ++e) {
                     const u32 row = idv[e] & ~kTailMark;
-                    const u32 moved = tail_remap(row, tt, lay_first);
-                    idv[e] = (idv[e] & kTailMark) ? (row >= layV ? moved : row) : idv[e];
+                    if ((idv[e] & kTailMark) && row >= layV)
+                        idv[e] = __float_as_uint(__builtin_nontemporal_load(a.lay_verts + (size_t)min(row, layEnd - 1u) * 3));
+                    else idv[e] = row;
                 }
             }
 #pragma unroll
@@ -1626,7 +1590,9 @@ __global__ void __launch_bounds__(kBlock) k_faces(const u64* __restrict__ bits, 
             if (i0 == 0) FSTAMP_NOWAIT(8);   // first batch: stores issued
 #endif
         }
-    }
+    };
+    if (per_id) batches(std::true_type{});
+    else batches(std::false_type{});
 #if P3D_FACES_STAMP
     FSTAMP_NOWAIT(9);
     stamp[11] = rel;
@@ -2090,8 +2056,7 @@ int count_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const p3
 
 template <typename T>
 int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xform& t, const p3d_mc_slab* slab,
-              char* ws, float* verts, int64_t capv, int32_t* faces, int64_t capf, int64_t* keys, hipStream_t st,
-              bool layout_form = false) {
+              char* ws, float* verts, int64_t capv, int32_t* faces, int64_t capf, int64_t* keys, hipStream_t st) {
     const int halo = slab ? slab->halo_last_plane : 0;
     u64* bits = (u64*)(ws + w.bits);
     uint2* rec = (uint2*)(ws + w.rec);
@@ -2111,8 +2076,7 @@ int emit_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xfo
     }
     if (w.nb_f > 0 && capf > 0) {
         StageTimer tm(ST_EMIT_FACES, st);
-        // (faces alone behind a call with a region layout: rows, translated with the tail tables the header still holds)
-        const FaceArgs a{layout_form ? 3 : 2, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
+        const FaceArgs a{2, halo, slab ? slab->vertex_id_base : 0, slab ? slab->halo_vertex_id_base : 0,
                          slab ? slab->rank_counts : nullptr, slab ? slab->rank : 0,
                          (slab && slab->rank_counts_stride > 0) ? slab->rank_counts_stride : 1, w.tpp, w.xw, (int)w.cpi,
                          (const u32*)(ws + w.chunk_sum), nullptr, (const u32*)(ws + w.wave_off),
@@ -2334,10 +2298,10 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     if (slab && slab->region_first_rows) {
         if (part != 0 || halo || !verts || capv <= 0)
             return fail(P3D_EINVAL, "region_first_rows: whole-grid calls (part 0, no halo plane) with a vertex buffer only%s");
-        for (int r = 0; r <= kRegions; ++r) lay_v.first[r] = slab->region_first_rows[r];
-        bool ok = lay_v.first[0] == 0u && (int64_t)lay_v.first[kRegions] <= capv && lay_v.first[kRegions] < 0x7fffff00u;
-        for (int r = 0; r < kRegions; ++r) ok = ok && lay_v.first[r] < lay_v.first[r + 1];
-        if (!ok) return fail(P3D_EINVAL, "region_first_rows must be 33 strictly ascending rows from 0 to at most cap_vertices%s");
+        for (int r = 0; r <= kRegions + 1; ++r) lay_v.first[r] = slab->region_first_rows[r];
+        bool ok = lay_v.first[0] == 0u && (int64_t)lay_v.first[kRegions + 1] <= capv && lay_v.first[kRegions + 1] < 0x7fffff00u;
+        for (int r = 0; r <= kRegions; ++r) ok = ok && lay_v.first[r] <= lay_v.first[r + 1];
+        if (!ok) return fail(P3D_EINVAL, "region_first_rows must be 34 ascending rows from 0 to at most cap_vertices%s");
         lay_v.on = 1u;
         lay = &lay_v;
     }
@@ -2430,8 +2394,9 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
             launch_count_walk(dim3((u32)(w.nchunks + cpe.nblocks)), st, bits, d, w, csum, woff, (u32*)(ws + w.tile_tris), cpe, hdr);
             if (cpre) hipLaunchKernelGGL(k_chunk_prefix, dim3(1), dim3(1024), 0, st, csum, (int)w.nchunks, cpre);
         }
-        const FaceArgs a{3, 0, 0, 0, nullptr, 0, 1, w.tpp, w.xw, (int)w.cpi, csum, cpre, woff, (const u32*)(ws + w.tile_tris),
-                         cursors, mb_l, seq_l};
+        FaceArgs a{3, 0, 0, 0, nullptr, 0, 1, w.tpp, w.xw, (int)w.cpi, csum, cpre, woff, (const u32*)(ws + w.tile_tris),
+                   cursors, mb_l, seq_l};
+        a.lay_verts = verts;
         CompactArgs cp{nullptr, verts, capv, 0, region_rows, 1, 0, 1, 1, csum, (int)w.nchunks, cursors, id_limit, 1, nullptr};
         cp.layout = 1;
         StageTimer tm(ST_EMIT_FACES, st);
@@ -2802,9 +2767,8 @@ int p3d_mc_emit(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz,
     // pass into the exactly sized buffers.  Ids handed out before must survive in every other case -- a slab (its first
     // plane's records may already be with the neighbour), vertices or faces alone, the keys of the parity tests, ids
     // renumbered by p3d_mc_count_scan -- and there the gather emitter writes by id.
-    if (next.layout && !(cap_vertices > 0 && cap_faces > 0) && cap_vertices > 0)
-        return fail(P3D_EINVAL, "behind a call with a region layout p3d_mc_emit takes both buffers (it streams the field again) or "
-                                "faces alone%s");
+    if (next.layout && !(cap_vertices > 0 && cap_faces > 0))
+        return fail(P3D_EINVAL, "behind a call with a region layout p3d_mc_emit takes both buffers (it streams the field again)%s");
     if (next.layout && (slab || vertex_keys))
         return fail(P3D_EINVAL, "behind a call with a region layout p3d_mc_emit takes neither a slab nor vertex_keys%s");
     if (!slab && !vertex_keys && cap_vertices > 0 && cap_faces > 0 && next.phase != PH_COUNT_SCAN) {
@@ -2819,9 +2783,9 @@ int p3d_mc_emit(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz,
     }
     if (dtype == P3D_F32)
         return emit_impl((const float*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices, faces,
-                         cap_faces, vertex_keys, st, next.layout);
+                         cap_faces, vertex_keys, st);
     return emit_impl((const __half*)grid, d, w, thresh, t, slab, (char*)ws, vertices, cap_vertices, faces,
-                     cap_faces, vertex_keys, st, next.layout);
+                     cap_faces, vertex_keys, st);
 }
 
 int p3d_mc_extract_fused(const void* grid, int dtype, int64_t rx, int64_t ry, int64_t rz, float thresh,

@@ -1,9 +1,11 @@
 """The predicted region layout of the one-pass call (p3d_mc_slab.region_first_rows, include/p3d_mc.h): the streaming kernel
-stores every vertex at its region's first row + slot inside the CALLER's vertex buffer -- final unless the row lies at or
-beyond V; those few rows are moved into the free rows the slack left below V and the face kernel translates their ids.  No
-scratch, no second trip.  Whole meshes against the oracle (keys rebuilt from the workspace: tests/ws_keys.py also checks the
-header's tail tables against their definition), for layouts that fit exactly, with slack, from another field, and for one
-that does not fit (flag 4 -> p3d_mc_emit)."""
+stores every vertex at its region's first row + slot inside the CALLER's vertex buffer; a wave-plane that does not fit into
+what is left of its region takes rows of the spill area behind the regions.  Rows are final unless they lie at or beyond V;
+those few are moved into the free rows below V and the face kernel translates their ids.  No scratch, no second trip.
+Whole meshes against the oracle (keys rebuilt from the workspace: tests/ws_keys.py also checks the header's tail tables
+against their definition and that every id is assigned once), for layouts that predict every region exactly, too few rows
+(spills), too many (holes; the top of the last region beyond V), both, none at all for some regions, the totals of another
+field, and a spill area that is too small (flag 4 -> p3d_mc_emit)."""
 import ctypes
 
 import numpy as np
@@ -54,9 +56,25 @@ CASES = [((40, 50, 517), "perlin"), ((33, 30, 1100), "perlin"), ((130, 131, 200)
          ((9, 100, 129), "perlin"), ((200, 96, 512), "perlin")]
 
 
+def _prediction(kind, regions):
+    """(extra rows per region relative to what it needs, rows of the spill area)"""
+    n = [int(r) for r in regions]
+    if kind == "exact":
+        return [0] * 32, 64
+    if kind == "under":     # every third region is given a tenth less than it needs: its last wave-planes spill
+        return [-(v // 10) if r % 3 == 0 else 0 for r, v in enumerate(n)], sum(n) // 8 + 4096
+    if kind == "over":      # every region a seventh more: holes behind all of them, the top regions lie beyond V
+        return [v // 7 + 5 for v in n], 256
+    if kind == "mixed":
+        return [(-(v // 6) if r % 2 else v // 9 + 3) for r, v in enumerate(n)], sum(n) // 5 + 4096
+    if kind == "none_for_some":   # regions 4..11 are given no rows at all: everything of theirs spills
+        return [-v if 4 <= r < 12 else 0 for r, v in enumerate(n)], sum(n) // 2 + 4096
+    raise KeyError(kind)
+
+
 @pytest.mark.parametrize("shape,kind", CASES)
-@pytest.mark.parametrize("slack", ["exact", "pad", "wide"])
-def test_layout_from_the_same_fields_totals(gpu, shape, kind, slack):
+@pytest.mark.parametrize("pred", ["exact", "under", "over", "mixed", "none_for_some"])
+def test_layout_from_the_same_fields_totals(gpu, shape, kind, pred):
     from primitive3d_amd import capi
     from primitive3d_amd.fields import perlin_grid
     g = (torch.from_numpy(np.random.default_rng(3).standard_normal(shape).astype(np.float32)) if kind == "noise"
@@ -65,18 +83,21 @@ def test_layout_from_the_same_fields_totals(gpu, shape, kind, slack):
     ref = canonical_mesh(*oracle_extract(g.cpu().numpy(), 0.03, lower, upper))
     nv, nf, regions = _first_call(capi, g, 0.03, lower, upper)
     assert nv == ref[0].shape[0]
-    num, den, pad = {"exact": (0, 1, 1), "pad": (0, 1, 64), "wide": (1, 3, 500)}[slack]   # (a region must own a row at least)
-    first, rows = capi.region_layout(regions, num, den, pad)
+    extra, spill = _prediction(pred, regions)
+    first, rows = capi.region_layout(regions, spill, extra)
     ws, v, f, nv2, nf2, flags, regions2 = _layout_call(capi, g, 0.03, lower, upper, first, rows, nf, guard=32)
     assert (nv2, nf2, flags) == (nv, nf, 0) and regions2 == regions
     assert (v[rows:] == -7.0).all()   # nothing past the buffer it was given
     _same(_mesh(capi, ws, shape, v[:nv], f[:nf]), ref)
     assert int(f[:nf].max()) == nv - 1 and int(f[:nf].min()) == 0
+    if pred == "exact":   # every row is where it stays: nothing was moved, no id translated
+        hdr = ws[:8192].view(torch.int64).cpu()
+        assert int(hdr[760 + 33]) == 0   # H_TAIL_HP[33]: free rows below V
 
 
 def test_layout_from_another_fields_totals(gpu):
     """Per-frame extraction of a changing field: the layout comes from the frame before (other noise seed), the regions differ
-    by a few per cent, the slack takes it: flags 0, the whole mesh right; frames in turn, each laid out from its predecessor."""
+    by a few per cent, the spill area takes it: flags 0, the whole mesh right; frames in turn, each laid out from its predecessor."""
     from primitive3d_amd import capi
     from primitive3d_amd.fields import perlin_grid
     shape = (96, 120, 512)
@@ -84,13 +105,13 @@ def test_layout_from_another_fields_totals(gpu):
     for seed in (2, 3, 4):
         g = perlin_grid(shape, period=24, seed=seed).to(gpu)
         ref = canonical_mesh(*oracle_extract(g.cpu().numpy(), 0.0, [0.0] * 3, [1.0] * 3))
-        first, rows = capi.region_layout(regions, 1, 8, 256)
+        first, rows = capi.region_layout(regions)   # (exact regions + a tenth of the total as the spill area)
         ws, v, f, nv, nf, flags, regions = _layout_call(capi, g, 0.0, [0.0] * 3, [1.0] * 3, first, rows, 3 * ref[0].shape[0])
         assert flags == 0 and nv == ref[0].shape[0]
         _same(_mesh(capi, ws, shape, v[:nv], f[:nf]), ref)
 
 
-def test_a_region_that_outgrows_its_rows_is_flagged_and_re_emitted(gpu):
+def test_a_spill_area_that_is_too_small_is_flagged_and_the_mesh_re_emitted(gpu):
     from primitive3d_amd import capi
     from primitive3d_amd.fields import perlin_grid
     shape = (64, 72, 512)
@@ -98,22 +119,20 @@ def test_a_region_that_outgrows_its_rows_is_flagged_and_re_emitted(gpu):
     lower, upper = [0.0] * 3, [float(s) for s in shape]
     ref = canonical_mesh(*oracle_extract(g.cpu().numpy(), 0.0, lower, upper))
     nv, nf, regions = _first_call(capi, g, 0.0, lower, upper)
-    short = list(regions)
-    short[7] = regions[7] // 2   # region 7 gets half the rows it needs
-    first, rows = capi.region_layout(short, 0, 1, 16)
+    extra = [-(int(n) // 2) if r == 7 else 0 for r, n in enumerate(regions)]   # region 7 gets half the rows it needs ...
+    first, rows = capi.region_layout(regions, 100, extra)                      # ... and the spill area 100 rows
     ws, v, f, nv2, nf2, flags, regions2 = _layout_call(capi, g, 0.0, lower, upper, first, rows, nf)
     assert flags == 4 and (nv2, nf2) == (nv, nf) and regions2 == regions   # the COUNTS are right; the vertex buffer is not
     v2 = torch.empty((nv, 3), device=gpu)
     f2 = torch.empty((nf, 3), dtype=torch.int32, device=gpu)
     capi.emit(g, 0.0, lower, upper, ws, v2, f2)   # a second pass, every region at its final rows
     _same(_mesh(capi, ws, shape, v2, f2), ref)
-    # and the order check: behind a layout call there is no scratch to copy from (part 6), and vertices alone need the pass
-    ws3, v3, f3, *_ = _layout_call(capi, g, 0.0, lower, upper, *capi.region_layout(regions, 0, 1, 8), nf)
+    # and the order check: behind a layout call there is no scratch to copy from (part 6), and p3d_mc_emit takes both buffers
+    ws3, v3, f3, *_ = _layout_call(capi, g, 0.0, lower, upper, *capi.region_layout(regions, 64), nf)
     with pytest.raises(capi.P3DError, match="both buffers"):
         capi.emit(g, 0.0, lower, upper, ws3, v2, None)
-    f4 = torch.empty((nf, 3), dtype=torch.int32, device=gpu)
-    capi.emit(g, 0.0, lower, upper, ws3, None, f4)   # faces alone: the rows stay where they are
-    _same(_mesh(capi, ws3, shape, v3[:nv], f4), ref)
+    with pytest.raises(capi.P3DError, match="both buffers"):
+        capi.emit(g, 0.0, lower, upper, ws3, None, f2)
     slab = capi.Slab()
     slab.part = 6
     with pytest.raises(capi.P3DError, match="had none"):
@@ -126,9 +145,9 @@ def test_bad_layouts_are_refused(gpu):
     ws = torch.empty(capi.workspace_bytes(8, 8, 70), dtype=torch.uint8, device=gpu)
     v = torch.empty((4096, 3), device=gpu)
     f = torch.empty((4096, 3), dtype=torch.int32, device=gpu)
-    for rows in ([1] + list(range(1, 33)), list(range(0, 33 * 200, 200)), [0] * 33):   # first != 0; beyond the buffer; not ascending
+    for rows in ([1] + list(range(1, 34)), list(range(0, 34 * 200, 200)), [0] + list(range(40, 7, -1))):   # first != 0; beyond the buffer; descending
         slab = capi.Slab()
-        arr = (ctypes.c_uint32 * 33)(*rows)
+        arr = (ctypes.c_uint32 * 34)(*rows)
         slab.region_first_rows = ctypes.cast(arr, ctypes.c_void_p)
         with pytest.raises(capi.P3DError, match="region_first_rows"):
             capi.extract_fused_raw(g, 0.5, [0.0] * 3, [1.0] * 3, ws, v, f, slab=slab)
