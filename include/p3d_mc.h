@@ -121,20 +121,21 @@ typedef struct p3d_mc_slab {
                                     capacity guess before it has seen the totals (SlabExtractor's device path): one launch
                                     less on the stream per extraction */
     int32_t reserved;            /* 0 */
-    const uint32_t* region_first_rows; /* part 0 without a halo plane only (ABI v10), optional HOST pointer to 34 ascending row
-                                    numbers, [0] = 0, [33] <= cap_vertices: a PREDICTED LAYOUT of the streaming kernel's 32
+    const uint32_t* region_first_rows; /* part 0 without a halo plane only (ABI v10), optional HOST pointer to 41 ascending row
+                                    numbers, [0] = 0, [40] <= cap_vertices: a PREDICTED LAYOUT of the streaming kernel's 32
                                     output regions inside `vertices`.  Region r owns rows [ [r], [r+1] ): give it the rows it
                                     NEEDED in the last call on the shape (p3d_mc_read_counts_ex reports the 32 totals), without
-                                    slack; behind the regions, [ [32], [33] ) is a spill area (a tenth of the expected vertex
-                                    count is plenty for a slowly changing field).  The kernel stores a vertex at its region's
-                                    first row + slot; a wave-plane that does not fit into what is left of its region takes
-                                    rows of the spill area.  Rows are final unless they lie at or beyond V: those few are moved
-                                    into the free rows below V and the face kernel translates their ids.  No scratch buffer
-                                    (vertex_scratch may be NULL), no second trip for the other rows; a field extracted twice in
-                                    a row moves nothing.  The spill area overflowing sets bit 2 of the flags: the vertex buffer
-                                    is incomplete, call p3d_mc_emit with exactly sized buffers (a second pass over the field).
-                                    Behind such a call p3d_mc_emit takes both buffers (never one alone); part 6 is not available.  The rows
-                                    of `vertices` at and beyond V are the library's until the call's work is done. */
+                                    slack; behind the regions, [ [32+g], [33+g] ) is spill area g (g < 8: what the regions
+                                    4g .. 4g+3 cannot hold; a tenth of the expected vertex count over the eight is plenty for
+                                    a slowly changing field).  The kernel stores a vertex at its region's first row + slot; a
+                                    wave-plane that does not fit into what is left of its region takes rows of its spill area.
+                                    Rows are final unless they lie at or beyond V: those few are moved into the free rows below
+                                    V and the face kernel translates their ids.  No scratch buffer (vertex_scratch may be NULL),
+                                    no second trip for the other rows; a field extracted twice in a row moves nothing.  A spill
+                                    area overflowing sets bit 2 of the flags: the vertex buffer is incomplete, call p3d_mc_emit
+                                    with exactly sized buffers (a second pass over the field).  Behind such a call p3d_mc_emit
+                                    takes both buffers (never one alone); part 6 is not available.  The rows of `vertices` at
+                                    and beyond V are the library's until the call's work is done. */
 } p3d_mc_slab;
 
 /* Bytes of device scratch p3d_mc_count / p3d_mc_emit need for an [rx,ry,rz] grid.

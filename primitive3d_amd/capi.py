@@ -146,15 +146,17 @@ def read_counts_ex(ws):
 
 
 def region_layout(region_totals, spill_rows=None, extra=None):
-    """34 ascending rows for p3d_mc_slab.region_first_rows from the region totals of an earlier call: every region gets exactly
-    its total (+ `extra[r]`, tests), the spill area behind them `spill_rows` rows (default: a tenth of the total + 4096).
-    Returns (ctypes uint32 array to keep alive, rows the vertex buffer needs)."""
+    """41 ascending rows for p3d_mc_slab.region_first_rows from the region totals of an earlier call: every region gets exactly
+    its total (+ `extra[r]`, tests), the eight spill areas behind them `spill_rows` rows in all (default: a tenth of the total
+    + 4096).  Returns (ctypes uint32 array to keep alive, rows the vertex buffer needs)."""
     first = [0]
     for r, n in enumerate(region_totals):
         first.append(first[-1] + max(0, int(n) + (int(extra[r]) if extra is not None else 0)))
     total = first[-1]
-    first.append(total + (total // 10 + 4096 if spill_rows is None else int(spill_rows)))
-    return (ctypes.c_uint32 * 34)(*first), first[-1]
+    spill = total // 10 + 4096 if spill_rows is None else int(spill_rows)
+    for g in range(8):
+        first.append(first[-1] + (spill + 7 - g) // 8)
+    return (ctypes.c_uint32 * 41)(*first), first[-1]
 
 
 def emit(grid, thresh, lower, upper, ws, vertices, faces, vertex_keys=None, slab=None, full_res=None):

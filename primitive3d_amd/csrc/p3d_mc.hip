@@ -97,13 +97,13 @@ constexpr int kHdrBytes = 8192;   // [0,256) totals/flags; [256,4352) the 32 cur
 enum { H_V = 0, H_T = 1, H_FLAGS = 2, H_RECFORM = 3 /* 1: rec[].x still region * 2^26 + slot; 2: rec[].x is a row of the
                                                          region layout, rows at or beyond V are remapped (H_TAIL_*) */,
        H_CURSORS = 32 /* u64 index */, H_PREFIX = 32 + 32 * 16,
-       H_LAYOUT = 600 /* [34] first row of every region, of the spill area, and its end: copied there by the streaming kernel */,
-       // the 33 intervals of the layout (32 regions + the spill area), as the counting launch's riding block 0 leaves them:
-       H_LAY_OCC = 840 /* [33] rows interval i really holds */,
-       H_TAIL_TS = 640 /* [33] first row at or beyond V of interval i */, H_TAIL_TP = 680 /* [33] such rows in intervals < i */,
-       H_TAIL_HS = 720 /* [33] first free row below V behind interval i's rows */, H_TAIL_HP = 760 /* [34] free rows behind intervals < i */,
-       H_TAIL_TE = 800 /* [33] end of interval i's rows at or beyond V (= ts_i when it has none) */ };
-constexpr int kLayIv = 33;   // intervals of a region layout: the 32 regions and the spill area
+       H_LAYOUT = 600 /* [41] first row of every region and of every spill area, and the end: copied there by the streaming kernel */,
+       // the 40 intervals of the layout (32 regions + 8 spill areas), as the counting launch's riding block 0 leaves them:
+       H_LAY_OCC = 650 /* [40] rows interval i really holds */,
+       H_TAIL_TS = 700 /* [40] first row at or beyond V of interval i */, H_TAIL_TP = 750 /* [40] such rows in intervals < i */,
+       H_TAIL_HS = 800 /* [40] first free row below V behind interval i's rows */, H_TAIL_HP = 850 /* [41] free rows behind intervals < i */,
+       H_TAIL_TE = 900 /* [40] end of interval i's rows at or beyond V (= ts_i when it has none) */ };
+constexpr int kLayIv = 40;   // intervals of a region layout: the 32 regions and the 8 spill areas (kRegions + kSpillAreas)
 
 __host__ __device__ inline Dims make_dims(int64_t rx, int64_t ry, int64_t rz) {
     Dims d;
@@ -541,17 +541,17 @@ struct CompactArgs {
 };
 typedef float F4U __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access at 4-byte alignment
 typedef float F4A __attribute__((ext_vector_type(4)));
-// Region-layout mode (RegionLayout, fused_stream.inc).  33 intervals: the 32 regions and the spill area.  Interval i holds
+// Region-layout mode (RegionLayout, fused_stream.inc).  40 intervals: the 32 regions and the 8 spill areas.  Interval i holds
 // rows [first_i, first_i + occ_i): occ of a region = its fill mark if a wave-plane of it turned to the spill area, else
-// min(total, its rows); occ of the spill area = min(its cursor, its rows).  V = the sum of the 32 region totals (= the sum
+// min(total, its rows); occ of a spill area = min(its cursor, its rows).  V = the sum of the 32 region totals (= the sum
 // of all occ when the spill area did not overflow).  Rows at or beyond V ("tail") move into the free rows below V ("holes"),
 // k-th tail row -> k-th hole, both in ascending order -- one interval of each kind per layout interval:
 //     tail of i      [ts_i, ts_i + tl_i) = [max(first_i, V), max(first_i + occ_i, V))        tp_i = tail rows of intervals < i
 //     hole behind i  [hs_i, hs_i + hl_i) = [min(first_i + occ_i, V), min(first_(i+1), V))    hp_i = hole rows behind intervals < i
-// Every riding block works the tables out for itself (lane i < 33 = interval i); block 0 writes them into the header for
+// Every riding block works the tables out for itself (lane i < 40 = interval i); block 0 writes them into the header for
 // k_faces (and for tests/ws_keys.py).
 struct TailTables {
-    u32 V, ts, tl, tp, hs, hl, hp;   // lane i < 33: interval i's entries
+    u32 V, ts, tl, tp, hs, hl, hp;   // lane i < 40: interval i's entries
 };
 __device__ inline TailTables tail_tables(const u64* __restrict__ cursors, const u64* __restrict__ hdr_layout, u32* over_out,
                                          u32* occ_out) {
@@ -559,11 +559,12 @@ __device__ inline TailTables tail_tables(const u64* __restrict__ cursors, const 
     const bool mine = lane < kLayIv, region = lane < kRegions;
     const u32 first = mine ? (u32)hdr_layout[lane] : 0u, next = mine ? (u32)hdr_layout[lane + 1] : 0u;
     const u32 rows = next - first;
-    const u64 cur = region ? cursors[lane * kCursorStride] : (lane == kRegions ? cursors[kSpillWord] : 0ull);
+    const u64 cur = region ? cursors[lane * kCursorStride]
+                           : (mine ? cursors[(size_t)(4 * (lane - kRegions)) * kCursorStride + kSpillWord] : 0ull);
     const u64 fill = region ? cursors[lane * kCursorStride + kFillWord] : 0ull;
     const u32 occ = fill ? (u32)(fill - 1ull) : (u32)min(cur, (u64)rows);
     if (occ_out) *occ_out = occ;
-    if (over_out) *over_out = (__ballot(lane == kRegions && cur > (u64)rows) != 0ull) ? 1u : 0u;   // the spill area overflowed
+    if (over_out) *over_out = (__ballot(mine && !region && cur > (u64)rows) != 0ull) ? 1u : 0u;   // a spill area overflowed
     u64 v64 = region ? cur : 0ull;   // V counts every vertex, stored or not (the caller sizes its re-emission from it)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v64 += __shfl_xor(v64, o, 64);
@@ -576,13 +577,13 @@ __device__ inline TailTables tail_tables(const u64* __restrict__ cursors, const 
     t.hl = mine ? min(next, t.V) - t.hs : 0u;
     t.tp = wave_prefix_sum(t.tl) - t.tl;
     t.hp = wave_prefix_sum(t.hl) - t.hl;
-    if (!mine) {   // (never selected: the searches stay below 33)
+    if (!mine) {   // (never selected: the searches stay below 40)
         t.ts = t.tp = t.hp = 0xffffffffu;
         t.hs = 0u;
     }
     return t;
 }
-// the LAST lane i < 33 with tab_i <= key (tab non-decreasing over the lanes 0..32, ~0 beyond): ds_bpermute, ALL lanes active
+// the LAST lane i < 40 with tab_i <= key (tab non-decreasing over the lanes 0..39, ~0 beyond): ds_bpermute, ALL lanes active
 __device__ inline u32 last_not_above(u32 tab, u32 key) {
     u32 i = 0;
 #pragma unroll
@@ -2298,10 +2299,10 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     if (slab && slab->region_first_rows) {
         if (part != 0 || halo || !verts || capv <= 0)
             return fail(P3D_EINVAL, "region_first_rows: whole-grid calls (part 0, no halo plane) with a vertex buffer only%s");
-        for (int r = 0; r <= kRegions + 1; ++r) lay_v.first[r] = slab->region_first_rows[r];
-        bool ok = lay_v.first[0] == 0u && (int64_t)lay_v.first[kRegions + 1] <= capv && lay_v.first[kRegions + 1] < 0x7fffff00u;
-        for (int r = 0; r <= kRegions; ++r) ok = ok && lay_v.first[r] <= lay_v.first[r + 1];
-        if (!ok) return fail(P3D_EINVAL, "region_first_rows must be 34 ascending rows from 0 to at most cap_vertices%s");
+        for (int r = 0; r < kLayRows; ++r) lay_v.first[r] = slab->region_first_rows[r];
+        bool ok = lay_v.first[0] == 0u && (int64_t)lay_v.first[kLayRows - 1] <= capv && lay_v.first[kLayRows - 1] < 0x7fffff00u;
+        for (int r = 0; r + 1 < kLayRows; ++r) ok = ok && lay_v.first[r] <= lay_v.first[r + 1];
+        if (!ok) return fail(P3D_EINVAL, "region_first_rows must be 41 ascending rows from 0 to at most cap_vertices%s");
         lay_v.on = 1u;
         lay = &lay_v;
     }

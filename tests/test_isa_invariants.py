@@ -72,27 +72,42 @@ def test_cursor_atomic_is_scalar(device_asm):
 
 
 def test_async_atomic_results_are_left_alone(device_asm):
-    """`got` is an SGPR written by a scalar atomic that is still in flight when its asm statement ends.  Between
-    the atomic and the next hand-written lgkmcnt(0) wait no instruction may mention it -- a copy or a spill there would
-    read the stale value (a round-4 experiment did exactly that with a second scalar atomic: the compiler moved the
-    operand to another register pair in front of the wait)."""
+    """`got` is an SGPR written by a scalar atomic that is still in flight when its asm statement ends.  Until the
+    hand-written lgkmcnt(0) wait that hands it over nothing may read, copy or spill it -- a copy there reads the stale value
+    (round 4: a second scalar atomic made the compiler move the operand to another register pair in front of the wait;
+    round 6: a second hand-written wait on the same variable made it copy the register right in front of the real one).
+    Checked on the text, block by block (block placement is the compiler's, and the register is reused for other values in
+    blocks that run BEFORE the atomic but stand behind it in the file, so a scan in file order says nothing):
+      A. from the atomic to the end of its basic block no instruction mentions its destination;
+      B. in the basic block of every hand-written wait, between the block's label and the wait, no instruction READS a
+         register an atomic of the kernel writes.
+    What this cannot see -- a copy in a block in between -- shows as wrong vertex ids: tests/test_gpu_parity.py compares
+    them on every path (the counting pass's records alone included, since the round-6 case was masked by a later pass)."""
     for name, body in _kernels(device_asm, "k_fused").items():
         lines = body.split("\n")
-        checked = 0
-        for i, line in enumerate(lines):
-            m = re.match(r"\s*s_atomic_add (s\d+),", line)
-            if not m:
-                continue
-            dest = _sregs(m.group(1))
+        atomics = [(i, _sregs(m.group(1))) for i, ln in enumerate(lines) for m in [re.match(r"\s*s_atomic_add (s\d+),", ln)] if m]
+        assert len(atomics) >= 2, name
+        dests = set().union(*(d for _, d in atomics))
+        for i, dest in atomics:
             j = i + 1
-            while j < len(lines):
-                if "s_waitcnt lgkmcnt(0)" in lines[j] and ("ASMSTART" in lines[j - 1] or j - 1 == i):
-                    break   # (a hand-written wait: an asm statement of its own, or the line behind the atomic in the same one)
-                assert not (dest & _sregs(lines[j].split(";")[0])), (name, i, line.strip(), j, lines[j].strip())
+            if "s_waitcnt lgkmcnt(0)" in lines[j]:
+                continue   # (awaited inside its own asm statement: the spill area's atomic)
+            while j < len(lines) and not re.match(r"\s*\.LBB\w+:", lines[j]):
+                if "s_waitcnt lgkmcnt(0)" in lines[j] and "ASMSTART" in lines[j - 1]:
+                    break
+                assert not (dest & _sregs(lines[j].split(";")[0])), (name, "A", i, lines[i].strip(), j, lines[j].strip())
                 j += 1
-            assert j < len(lines), (name, "no wait behind", line.strip())
-            checked += 1
-        assert checked >= 2, name
+        waits = [j for j, ln in enumerate(lines) if "s_waitcnt lgkmcnt(0)" in ln and "ASMSTART" in lines[j - 1]]
+        assert len(waits) >= 2, name
+        for w in waits:
+            j = w - 2   # (w - 1 is the ASMSTART line)
+            while j >= 0 and not re.match(r"\s*\.LBB\w+:", lines[j]):
+                ins = lines[j].split(";")[0].strip()
+                m = re.match(r"(\S+)\s+([^,]+),(.*)", ins)
+                if m and not ins.startswith(("s_cbranch", "s_branch")):
+                    sources = _sregs(m.group(3))   # everything behind the first operand: what the instruction reads
+                    assert not (dests & sources), (name, "B", w, j, lines[j].strip())
+                j -= 1
 
 
 def test_no_scratch_in_the_benchmarked_variants(device_asm):

@@ -34,30 +34,30 @@ def vertex_keys_from_workspace(ws: np.ndarray, shape, nv: int, layout: dict, hal
         region = np.minimum(base >> 26, 31)
         base = (base & 0x3FFFFFF) + prefix[region]
     if int(hdr[3]) == 2:  # region-layout form: rec[].x is a ROW; rows at or beyond V were moved into the holes below V
-        H_LAYOUT, H_OCC, H_TS, H_TP, H_HS, H_HP, H_TE = 600, 840, 640, 680, 720, 760, 800
+        H_LAYOUT, H_OCC, H_TS, H_TP, H_HS, H_HP, H_TE, NI = 600, 650, 700, 750, 800, 850, 900, 40
         assert int(hdr[0]) == nv
-        first = hdr[H_LAYOUT:H_LAYOUT + 34].astype(np.int64)           # 32 regions, the spill area, its end
-        occ = hdr[H_OCC:H_OCC + 33].astype(np.int64)
-        ts, tp = hdr[H_TS:H_TS + 33].astype(np.int64), hdr[H_TP:H_TP + 33].astype(np.int64)
-        hs, hp = hdr[H_HS:H_HS + 33].astype(np.int64), hdr[H_HP:H_HP + 34].astype(np.int64)
+        first = hdr[H_LAYOUT:H_LAYOUT + NI + 1].astype(np.int64)       # 32 regions, 8 spill areas, the end
+        occ = hdr[H_OCC:H_OCC + NI].astype(np.int64)
+        ts, tp = hdr[H_TS:H_TS + NI].astype(np.int64), hdr[H_TP:H_TP + NI].astype(np.int64)
+        hs, hp = hdr[H_HS:H_HS + NI].astype(np.int64), hdr[H_HP:H_HP + NI + 1].astype(np.int64)
         counts = hdr[32:32 + 32 * 16:16].astype(np.int64)
-        assert counts.sum() == nv and (occ <= first[1:] - first[:33]).all() and occ.sum() == nv, "rows held != V (spill overflow?)"
+        assert counts.sum() == nv and (occ <= first[1:] - first[:NI]).all() and occ.sum() == nv, "rows held != V (spill overflow?)"
         assert (occ[:32] <= counts).all()
         # the tables against their definition (p3d_mc.hip: tail_tables)
-        end = first[:33] + occ
-        assert (ts == np.maximum(first[:33], nv)).all() and (hs == np.minimum(end, nv)).all()
+        end = first[:NI] + occ
+        assert (ts == np.maximum(first[:NI], nv)).all() and (hs == np.minimum(end, nv)).all()
         tl, hl = np.maximum(end, nv) - ts, np.minimum(first[1:], nv) - hs
-        assert (hdr[H_TE:H_TE + 33].astype(np.int64) == ts + tl).all()
-        assert (tp == np.cumsum(tl) - tl).all() and (hp[:33] == np.cumsum(hl) - hl).all() and hp[33] == hl.sum() == tl.sum()
+        assert (hdr[H_TE:H_TE + NI].astype(np.int64) == ts + tl).all()
+        assert (tp == np.cumsum(tl) - tl).all() and (hp[:NI] == np.cumsum(hl) - hl).all() and hp[NI] == hl.sum() == tl.sum()
 
         def to_dense(row):   # ids of a unit, one by one (a unit's run may be split by the move)
             out = row.copy()
             m = row >= nv
             r = row[m]
-            j = np.searchsorted(first[:33], r, side="right") - 1
+            j = np.searchsorted(first[:NI], r, side="right") - 1
             assert (r < first[j] + occ[j]).all(), "an id beyond its interval's rows"
             kk = tp[j] + (r - ts[j])
-            i = np.searchsorted(hp[:33], kk, side="right") - 1
+            i = np.searchsorted(hp[:NI], kk, side="right") - 1
             out[m] = hs[i] + (kk - hp[i])
             return out
     else:
