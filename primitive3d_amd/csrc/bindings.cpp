@@ -41,6 +41,12 @@ struct CapHint {
     int64_t peak_v = 0;   // the most vertices any call on this shape produced: bounds the vertex SCRATCH (below)
     int slack_q = 5;  // headroom of every scratch region in quarters (5 = 1.25x); doubles after a region overflow ...
     int clean_calls = 0;   // ... and halves again after kSlackDecayCalls calls in a row without one (it used to stay for good)
+    // the predicted region layout (p3d_mc_slab.region_first_rows): the 32 region totals of the last call on the shape, the vertex
+    // counts of the last two (a layout is tried when they are within a quarter of each other: a stream of similar frames), and
+    // calls left to sit out after a spill area overflowed
+    int64_t regions[32] = {0};
+    int64_t last_v = -1, prev_v = -1;
+    int layout_cooldown = 0;
     uint64_t last_use = 0;
     int64_t max_v() const { return *std::max_element(nv, nv + kHintCalls); }
     int64_t max_f() const { return *std::max_element(nf, nf + kHintCalls); }
@@ -110,6 +116,8 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     // 32 independently filled regions: `slack` is the headroom per region, and every region can hold 8192 rows
     // because a small output may come from very few wave-planes.  Returns true when everything fitted.
     bool region_overflow = false, id_overflow = false, scratch_overflow = false;
+    int64_t last_regions[32] = {0};   // the streaming kernel's 32 region totals of the last pass (what a layout is made from)
+    bool have_last_regions = false;
     // The scratch is sized for the LARGER of the expectation and a guess: it is memory of this call only, and a field that
     // turns out denser than the last few calls on its shape -- or than the guess of a first call -- then only outgrows the
     // OUTPUT buffers: the faces and the compaction run again into larger ones (below), the field is not streamed twice.
@@ -139,7 +147,8 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
                                       capf ? faces.data_ptr<int32_t>() : nullptr, capf, stream),
                  "p3d_mc_extract_fused");
         int32_t overflow = 0;
-        check_rc(p3d_mc_read_counts(ws.data_ptr(), &nv, &nf, &overflow, stream), "p3d_mc_read_counts");
+        check_rc(p3d_mc_read_counts_ex(ws.data_ptr(), &nv, &nf, &overflow, last_regions, stream), "p3d_mc_read_counts_ex");
+        have_last_regions = true;
         scratch_overflow = (overflow & 1) != 0;
         region_overflow = scratch_overflow && nv <= capv;  // the total fitted, the split over the regions did not
         id_overflow = (overflow & 2) != 0;                     // a region outgrew its id space: renumber (below)
@@ -166,6 +175,84 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
         } else {
             capv = std::max<int64_t>(4096, rx * ry * rz / 16);
             capf = 2 * capv;
+        }
+    }
+    // Steady state of the default mode: the streaming kernel stores every vertex where it STAYS.  The 32 output regions are laid
+    // out inside the vertex tensor itself from the region totals of the last call on this shape (exactly: a field extracted twice
+    // in a row moves nothing; a changed field lets the regions that grew spill into eight small areas behind them, and the few
+    // rows that end up beyond V are moved down by blocks riding in the counting launch).  No scratch tensor, no copy of the
+    // vertex rows.  Tried when the last two calls on the shape were of similar size; a spill area overflowing (flag 4) costs a
+    // second pass over the field into exactly sized tensors and two calls in the scratch mode below.
+    int64_t lay_regions[32];
+    bool use_layout = false;
+    static const bool layout_off = [] { const char* m = std::getenv("P3D_MC_LAYOUT"); return m && std::string(m) == "0"; }();
+    {
+        std::lock_guard<std::mutex> g(g_cap_mu);
+        auto it = g_cap_hint.find(key);
+        if (!exact_mode && !layout_off && it != g_cap_hint.end()) {
+            CapHint& h = it->second;
+            if (h.layout_cooldown > 0) {
+                --h.layout_cooldown;
+            } else if (h.last_v > 0 && h.prev_v > 0 && 4 * h.last_v >= 3 * h.prev_v && 4 * h.prev_v >= 3 * h.last_v) {
+                use_layout = true;
+                std::copy(h.regions, h.regions + 32, lay_regions);
+            }
+        }
+    }
+    if (use_layout) {
+        uint32_t first[41];
+        int64_t row = 0;
+        for (int r = 0; r < 32; ++r) {
+            first[r] = (uint32_t)row;
+            row += lay_regions[r];
+        }
+        const int64_t spill = row / 8 + 4096;   // the eight areas together
+        for (int a = 0; a < 8; ++a) {
+            first[32 + a] = (uint32_t)row;
+            row += (spill + 7 - a) / 8;
+        }
+        first[40] = (uint32_t)row;
+        use_layout = row < (int64_t)0x7fff0000;
+        if (use_layout) {
+            const int64_t capv_l = row;
+            vertices = torch::empty({capv_l, 3}, vopt);
+            if (capf > 0) faces = torch::empty({capf, 3}, fopt);
+            p3d_mc_slab lay{};
+            lay.region_first_rows = first;
+            check_rc(p3d_mc_extract_fused(grid, dtype, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, &lay, ws.data_ptr(),
+                                          vertices.data_ptr<float>(), capv_l, nullptr, 0, capf ? faces.data_ptr<int32_t>() : nullptr,
+                                          capf, stream),
+                     "p3d_mc_extract_fused");
+            int32_t overflow = 0;
+            int64_t regs[32];
+            check_rc(p3d_mc_read_counts_ex(ws.data_ptr(), &nv, &nf, &overflow, regs, stream), "p3d_mc_read_counts_ex");
+            const bool fitted = !overflow && nf <= capf;
+            {
+                std::lock_guard<std::mutex> g(g_cap_mu);
+                CapHint& h = g_cap_hint[key];
+                h.record(nv, nf);
+                h.prev_v = h.last_v;
+                h.last_v = nv;
+                std::copy(regs, regs + 32, h.regions);
+                if (overflow & 4) h.layout_cooldown = 2;
+                h.last_use = ++g_cap_clock;
+            }
+            if (!fitted) {   // (a spill area overflowed, or the faces outgrew their tensor: exactly sized tensors, a second pass)
+                vertices = torch::empty({nv, 3}, vopt);
+                faces = torch::empty({nf, 3}, fopt);
+                if (nv > 0 && nf > 0)
+                    check_rc(p3d_mc_emit(grid, dtype, rx, ry, rz, thresh, lower.data(), upper.data(), nullptr, nullptr, ws.data_ptr(),
+                                         vertices.data_ptr<float>(), nv, faces.data_ptr<int32_t>(), nf, nullptr, stream),
+                             "p3d_mc_emit");
+                return {vertices, faces};
+            }
+            auto fit_l = [&](Tensor& t, int64_t n, int64_t cap) {
+                if (n != cap) t = 2 * n >= cap ? t.narrow(0, 0, n) : t.narrow(0, 0, n).clone();
+            };
+            fit_l(vertices, nv, capv_l);
+            if (capf > 0) fit_l(faces, nf, capf);
+            else faces = torch::empty({0, 3}, fopt);
+            return {vertices, faces};
         }
     }
     // P3D_MC_MODE=exact: the reference's order -- count, read (V, F), allocate exactly, emit (marching_cubes.cu:242-287) --
@@ -213,6 +300,9 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
         }
         CapHint& h = g_cap_hint[key];
         h.record(nv, nf);
+        h.prev_v = h.last_v;
+        h.last_v = have_last_regions && !id_overflow ? nv : -1;
+        if (have_last_regions) std::copy(last_regions, last_regions + 32, h.regions);
         constexpr int kSlackDecayCalls = 64;
         if (region_overflow) {
             h.slack_q = std::min(2 * slack_q, 32);
