@@ -303,7 +303,7 @@ int p3d_mc_shutdown(void);
 
 /* Counters of what the library has launched since it was loaded (no reference counterpart; tests and the bench read them
  * to see which path a call took -- nothing in the data path depends on them):
- *   out[0] streaming launches                            out[1] always 0 (was: launches with the round-4 plane hand-out)
+ *   out[0] streaming launches          out[1] streaming passes that stored through a region layout (p3d_mc_slab.region_first_rows)
  *   out[2] streaming passes of p3d_mc_extract_fused[_batched] that wrote or counted a whole grid / stack (part 0 or 2, 3)
  *   out[3] calls of p3d_mc_count / p3d_mc_count_scan
  *   out[4] emissions that had no streaming pass of their own (p3d_mc_slab.part = 6)

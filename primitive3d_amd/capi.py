@@ -190,7 +190,7 @@ def debug_counters():
     out = (c_int64 * 7)()
     n = lib().p3d_mc_debug_counters(out, 7)
     assert n == 7, n
-    return {"streaming_launches": out[0], "streaming_passes": out[2], "count_emit_calls": out[3],
+    return {"streaming_launches": out[0], "layout_passes": out[1], "streaming_passes": out[2], "count_emit_calls": out[3],
             "emissions_without_a_pass": out[4], "stream_rings": out[5], "ring_bytes": out[6]}
 
 

@@ -41,10 +41,10 @@ struct CapHint {
     int64_t peak_v = 0;   // the most vertices any call on this shape produced: bounds the vertex SCRATCH (below)
     int slack_q = 5;  // headroom of every scratch region in quarters (5 = 1.25x); doubles after a region overflow ...
     int clean_calls = 0;   // ... and halves again after kSlackDecayCalls calls in a row without one (it used to stay for good)
-    // the predicted region layout (p3d_mc_slab.region_first_rows): the 32 region totals of the last call on the shape, the vertex
-    // counts of the last two (a layout is tried when they are within a quarter of each other: a stream of similar frames), and
-    // calls left to sit out after a spill area overflowed
-    int64_t regions[32] = {0};
+    // the predicted region layout (p3d_mc_slab.region_first_rows): the 32 region totals of the last TWO calls on the shape (a
+    // layout is made from the last call's when they moved by less than kLayoutDrift of the vertices between the two: a field
+    // that stands still or changes slowly), their vertex counts, and calls left to sit out after a spill area overflowed
+    int64_t regions[32] = {0}, prev_regions[32] = {0};
     int64_t last_v = -1, prev_v = -1;
     int layout_cooldown = 0;
     uint64_t last_use = 0;
@@ -55,6 +55,21 @@ struct CapHint {
         nf[n % kHintCalls] = f;
         peak_v = std::max(peak_v, v);
         ++n;
+    }
+    // the region totals of a pass (null: the pass left none that a layout could be made from)
+    void record_regions(const int64_t* r, int64_t v) {
+        std::copy(regions, regions + 32, prev_regions);
+        prev_v = last_v;
+        if (r) std::copy(r, r + 32, regions);
+        last_v = r ? v : -1;
+    }
+    // rows that changed region between the last two calls, as a measure of how far off a layout made from the last call will be
+    bool regions_stand_still() const {
+        constexpr int64_t kLayoutDrift = 20;   // 1/20 of the vertices: up to there a layout beats the scratch (profiles/r06/README.md)
+        if (last_v <= 0 || prev_v <= 0) return false;
+        int64_t moved = 0;
+        for (int r = 0; r < 32; ++r) moved += std::abs(regions[r] - prev_regions[r]);
+        return moved * kLayoutDrift <= last_v;
     }
 };
 std::map<CapKey, CapHint> g_cap_hint;   // at most kMaxHints shapes; when full, the least recently used one goes
@@ -101,16 +116,20 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
 
     // P3D_MC_MODE (the one environment variable this module reads; INTEGRATION.md section 2 says why the default is what it is):
     //   hinted (default)  rows [0, V) / [0, F) of buffers sized from the last calls on this grid shape, which may be up to
-    //                     1/8 + 4096 rows longer; no host round trip inside the call
+    //                     1/8 + 4096 rows longer; no host round trip inside the call.  On a field that stands still or changes
+    //                     slowly the vertices are stored where they stay (the predicted region layout below), otherwise they
+    //                     go through a scratch tensor of this call
+    //   scratch           hinted, always through the scratch tensor (what `hinted` was until round 6; for A/B measurements)
     //   exact             freshly allocated tensors that own exactly V / F rows, like the reference's torch::zeros({V,3})
     //                     (marching_cubes.cu:260-263), in the reference's order count -> read -> allocate -> emit (below);
     //                     no state is carried from call to call except the vertex-scratch sizing
     static const bool exact_mode = [] {
         const char* m = std::getenv("P3D_MC_MODE");
-        TORCH_CHECK(!m || !*m || std::string(m) == "exact" || std::string(m) == "hinted",
-                    "P3D_MC_MODE must be 'hinted' or 'exact', got '", m, "'");
+        TORCH_CHECK(!m || !*m || std::string(m) == "exact" || std::string(m) == "hinted" || std::string(m) == "scratch",
+                    "P3D_MC_MODE must be 'hinted', 'scratch' or 'exact', got '", m, "'");
         return m && std::string(m) == "exact";
     }();
+    static const bool layout_off = [] { const char* m = std::getenv("P3D_MC_MODE"); return m && std::string(m) == "scratch"; }();
 
     // One streaming pass into buffers of the given capacities (0,0 = count only).  The vertex scratch is cut into
     // 32 independently filled regions: `slack` is the headroom per region, and every region can hold 8192 rows
@@ -181,11 +200,11 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     // out inside the vertex tensor itself from the region totals of the last call on this shape (exactly: a field extracted twice
     // in a row moves nothing; a changed field lets the regions that grew spill into eight small areas behind them, and the few
     // rows that end up beyond V are moved down by blocks riding in the counting launch).  No scratch tensor, no copy of the
-    // vertex rows.  Tried when the last two calls on the shape were of similar size; a spill area overflowing (flag 4) costs a
-    // second pass over the field into exactly sized tensors and two calls in the scratch mode below.
+    // vertex rows.  Tried when fewer than 1/20 of the vertices changed region between the last two calls on the shape (beyond that
+    // the regions that grew send every wave-plane to a second cursor and the scratch is the faster way); a spill area overflowing
+    // (flag 4) costs a second pass over the field into exactly sized tensors and two calls in the scratch mode below.
     int64_t lay_regions[32];
     bool use_layout = false;
-    static const bool layout_off = [] { const char* m = std::getenv("P3D_MC_LAYOUT"); return m && std::string(m) == "0"; }();
     {
         std::lock_guard<std::mutex> g(g_cap_mu);
         auto it = g_cap_hint.find(key);
@@ -193,7 +212,7 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
             CapHint& h = it->second;
             if (h.layout_cooldown > 0) {
                 --h.layout_cooldown;
-            } else if (h.last_v > 0 && h.prev_v > 0 && 4 * h.last_v >= 3 * h.prev_v && 4 * h.prev_v >= 3 * h.last_v) {
+            } else if (h.regions_stand_still()) {
                 use_layout = true;
                 std::copy(h.regions, h.regions + 32, lay_regions);
             }
@@ -231,9 +250,7 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
                 std::lock_guard<std::mutex> g(g_cap_mu);
                 CapHint& h = g_cap_hint[key];
                 h.record(nv, nf);
-                h.prev_v = h.last_v;
-                h.last_v = nv;
-                std::copy(regs, regs + 32, h.regions);
+                h.record_regions(overflow & 2 ? nullptr : regs, nv);
                 if (overflow & 4) h.layout_cooldown = 2;
                 h.last_use = ++g_cap_clock;
             }
@@ -300,9 +317,7 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
         }
         CapHint& h = g_cap_hint[key];
         h.record(nv, nf);
-        h.prev_v = h.last_v;
-        h.last_v = have_last_regions && !id_overflow ? nv : -1;
-        if (have_last_regions) std::copy(last_regions, last_regions + 32, h.regions);
+        h.record_regions(have_last_regions && !id_overflow ? last_regions : nullptr, nv);
         constexpr int kSlackDecayCalls = 64;
         if (region_overflow) {
             h.slack_q = std::min(2 * slack_q, 32);

@@ -2344,6 +2344,7 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
     }
     if (part < 4) {
         if (part != 1) g_counters[2].fetch_add(1, std::memory_order_relaxed);
+        if (lay) g_counters[1].fetch_add(1, std::memory_order_relaxed);
         const int stage = part == 1 ? ST_FUSED_INTERIOR : ST_FUSED;
         const bool timed = g_prof_mode != 0;
         if (timed) g_ev_used[stage] = true;

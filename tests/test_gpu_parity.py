@@ -405,11 +405,13 @@ def test_ply_of_a_device_resident_extraction(gpu, built, tmp_path):
     assert p.read_bytes() == reference_ply_bytes(vn, fn, colors.cpu().numpy())
 
 
-@pytest.mark.parametrize("env", [{"P3D_MC_MODE": "exact"}, {"P3D_MC_MODE": "hinted"}, {}, {"P3D_MC_MODE": "fast"}])
+@pytest.mark.parametrize("env", [{"P3D_MC_MODE": "exact"}, {"P3D_MC_MODE": "hinted"}, {"P3D_MC_MODE": "scratch"}, {},
+                                 {"P3D_MC_MODE": "fast"}])
 def test_adapter_modes_in_a_fresh_process(gpu, env):
     """The pybind adapter's one switch is read once per process: `P3D_MC_MODE=exact` (the reference's own order: count,
-    read, allocate exactly, emit) or `hinted` (the default).  Each must give the oracle's counts on repeated calls; with
-    exact allocations the storage sizes are exact; any other value is an error, not a silent default."""
+    read, allocate exactly, emit), `hinted` (the default: from the third call on a field that stands still, the vertices are
+    stored where they stay) or `scratch` (hinted, always through the scratch tensor).  Each must give the oracle's counts on
+    repeated calls; with exact allocations the storage sizes are exact; any other value is an error, not a silent default."""
     import os
     import subprocess
     import sys
@@ -420,13 +422,13 @@ def test_adapter_modes_in_a_fresh_process(gpu, env):
             "from tests.cases import small_cases\n"
             "g, t, lo, up = small_cases()['noise_33x17x200']\n"
             "x = torch.from_numpy(g).cuda()\n"
-            "for _ in range(3):\n"
+            "for _ in range(5):\n"
             "    v, f = p3d.libPrim3D.marching_cubes(x, t, lo, up)\n"
             "torch.cuda.synchronize()\n"
             "print(v.shape[0], f.shape[0], v.untyped_storage().nbytes() // 12, f.untyped_storage().nbytes() // 12)\n") % str(root)
     out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=300)
     if env.get("P3D_MC_MODE") == "fast":
-        assert out.returncode != 0 and "P3D_MC_MODE must be 'hinted' or 'exact'" in out.stderr, out.stderr[-2000:]
+        assert out.returncode != 0 and "P3D_MC_MODE must be 'hinted', 'scratch' or 'exact'" in out.stderr, out.stderr[-2000:]
         return
     assert out.returncode == 0, out.stderr[-2000:]
     g, t, _, _ = small_cases()["noise_33x17x200"]

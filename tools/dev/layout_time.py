@@ -16,6 +16,9 @@ ws = torch.empty(capi.workspace_bytes(*shape), dtype=torch.uint8, device="cuda")
 capv0 = shape[0] * shape[1] * shape[2] // 16
 v0 = torch.empty((capv0, 3), device="cuda"); f = torch.empty((2 * capv0, 3), dtype=torch.int32, device="cuda")
 scratch = torch.empty((capi.scratch_rows_for(capv0), 3), device="cuda")
+import random
+rng = random.Random(1)
+JIT = float(os.environ.get("JIT", "0"))
 state = {"regions": None, "i": 0, "over": 0}
 def call_scratch():
     g = grids[state["i"] % ngr]; state["i"] += 1
@@ -25,7 +28,10 @@ def call_scratch():
     return nv, nf, fl
 def call_layout():
     g = grids[state["i"] % ngr]; state["i"] += 1
-    first, rows = capi.region_layout(state["regions"])
+    reg = state["regions"]
+    if JIT:   # a prediction that is off by up to JIT per region (a slowly changing field)
+        reg = [max(0, int(r * (1 + JIT * (2 * rng.random() - 1)))) for r in reg]
+    first, rows = capi.region_layout(reg)
     v = torch.empty((rows, 3), device="cuda")
     slab = capi.Slab(); slab.region_first_rows = ctypes.cast(first, ctypes.c_void_p)
     capi.extract_fused_raw(g, 0.0, [0, 0, 0], up, ws, v, f, slab=slab)
@@ -55,4 +61,6 @@ def measure(call, label):
     print(label, "V", r[0], "F", r[1], "flags", r[2], "call_us median %.1f min %.1f" % (walls[2], walls[0]), st, "layout overflows", state["over"])
 for rep in range(int(os.environ.get("REPS", "2"))):
     measure(call_scratch, "scratch")
-    measure(call_layout, "layout ")
+    for j in [float(x) for x in os.environ.get("JITS", str(JIT)).split(",")]:
+        JIT = j
+        measure(call_layout, "layout jit %.3f" % j)
