@@ -279,7 +279,7 @@ const char* p3d_mc_profile_stage_name(int stage);
  *   P3D_FACES_SPARSE   (rule)  the face launch's empty-tile pre-check: unset = chosen per launch from the face capacity,
  *                              0 = never, 1 = always (an object's SDF in a large box whose first call is already sparse)
  *   P3D_NO_MAILBOX     (0)     1 = p3d_mc_read_counts copies and synchronises instead of polling the pinned mailbox
- * The pybind adapter (libPrim3D) reads one more, P3D_MC_MODE = hinted (default) | exact.
+ * The pybind adapter (libPrim3D) reads one more, P3D_MC_MODE = hinted (default) | scratch | exact.
  * p3d_mc_reload_tuning re-reads the first five (tests; not to be called while another thread is inside the library).
  *
  * Everything else that used to be readable from the environment -- the developer sweeps' launch knobs and the TEST HOOKS

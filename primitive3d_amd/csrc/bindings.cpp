@@ -42,7 +42,7 @@ struct CapHint {
     int slack_q = 5;  // headroom of every scratch region in quarters (5 = 1.25x); doubles after a region overflow ...
     int clean_calls = 0;   // ... and halves again after kSlackDecayCalls calls in a row without one (it used to stay for good)
     // the predicted region layout (p3d_mc_slab.region_first_rows): the 32 region totals of the last TWO calls on the shape (a
-    // layout is made from the last call's when they moved by less than kLayoutDrift of the vertices between the two: a field
+    // layout is made from the last call's when they moved by less than 1/kLayoutDrift of the vertices between the two: a field
     // that stands still or changes slowly), their vertex counts, and calls left to sit out after a spill area overflowed
     int64_t regions[32] = {0}, prev_regions[32] = {0};
     int64_t last_v = -1, prev_v = -1;
@@ -65,7 +65,9 @@ struct CapHint {
     }
     // rows that changed region between the last two calls, as a measure of how far off a layout made from the last call will be
     bool regions_stand_still() const {
-        constexpr int64_t kLayoutDrift = 20;   // 1/20 of the vertices: up to there a layout beats the scratch (profiles/r06/README.md)
+        // 1/64 of the vertices: an iso level creeping by 1 % of the field's range per call moves 0.5-0.7 %, a different random field
+        // 1.5-4 % -- and from about 2.5 % on the scratch is the faster way (profiles/r06/layout_ab.txt)
+        constexpr int64_t kLayoutDrift = 64;
         if (last_v <= 0 || prev_v <= 0) return false;
         int64_t moved = 0;
         for (int r = 0; r < 32; ++r) moved += std::abs(regions[r] - prev_regions[r]);
@@ -200,7 +202,7 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
     // out inside the vertex tensor itself from the region totals of the last call on this shape (exactly: a field extracted twice
     // in a row moves nothing; a changed field lets the regions that grew spill into eight small areas behind them, and the few
     // rows that end up beyond V are moved down by blocks riding in the counting launch).  No scratch tensor, no copy of the
-    // vertex rows.  Tried when fewer than 1/20 of the vertices changed region between the last two calls on the shape (beyond that
+    // vertex rows.  Tried when fewer than 1/64 of the vertices changed region between the last two calls on the shape (beyond that
     // the regions that grew send every wave-plane to a second cursor and the scratch is the faster way); a spill area overflowing
     // (flag 4) costs a second pass over the field into exactly sized tensors and two calls in the scratch mode below.
     int64_t lay_regions[32];
