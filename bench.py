@@ -655,12 +655,14 @@ def main():
     # ---- the timed region: exactly K steps, nothing else on the stream ----
     barrier()
     torch.cuda.synchronize()
+    lay0 = capi.debug_counters()["layout_passes"]   # (a host-side counter of the library: no GPU work)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
+    laid_out = capi.debug_counters()["layout_passes"] - lay0
 
     # ---- the dominant kernel's duration, live, by hipEvents that ride on its own dispatch packet, on the steps that
     # follow immediately (same inputs, same stream, same back-to-back call pattern).  Not inside the timed region: an
@@ -791,6 +793,9 @@ def main():
                        # which allocation policy of the pybind adapter the headline ran: "hinted"
                        # (default) or "exact" (P3D_MC_MODE=exact; under `modes` when it is not the headline's)
                        "adapter_mode": (os.environ.get("P3D_MC_MODE") or "hinted") if world == 1 and batch == 1 else None,
+                       # how many of the K timed calls stored their vertices where they stay (the predicted region layout,
+                       # no scratch tensor, no copy of the vertex rows) -- K in the steady state of `hinted`
+                       "calls_with_region_layout": laid_out,
                        "voxels_per_gpu": local_vox, "vertices": nv, "faces": nf,
                        "partition": "none" if world == 1 else f"axis-0 slabs x{world}, 1-plane RCCL halo"},
             "roofline": roofline,

@@ -45,6 +45,9 @@ def test_default_run_reports_the_other_configs(gpu):
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
     assert d["metric"].startswith("Mvoxels/s on 512^3 fp32 SDF") and d["dtype"] == "f32" and d["steps"] == 3
     assert abs(d["value"] - 512 ** 3 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
+    # the steady state of the default adapter mode: every timed call stored its vertices where they stay (the two calls of the
+    # warm-up gave the region totals the layouts are made from)
+    assert d["config"]["adapter_mode"] == "hinted" and d["config"]["calls_with_region_layout"] == 3
     # the headline workload carries the measured HBM traffic of its dominant kernel and the fraction of the peak that the
     # kernel reaches on THOSE bytes (>= the fraction on the algorithmic bytes)
     r = d["roofline"]

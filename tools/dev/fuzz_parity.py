@@ -8,7 +8,7 @@ from oracle import oracle_extract
 from tests.test_gpu_parity import _assert_same_mesh, _hip_extract, _hip_extract_fused, _hip_extract_pair
 from oracle import canonical_mesh
 from primitive3d_amd import capi
-from tests.test_gpu_layout import _first_call, _layout_call, _mesh, _same
+from tests.test_gpu_layout import _layout_call, _mesh, _same
 rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
 n_flag4 = 0
 
@@ -18,7 +18,18 @@ def layout_leg(g, thresh, ref, dt):
     global n_flag4
     t = torch.from_numpy(np.ascontiguousarray(g)).to(gpu).to(dt)
     up = [float(v) for v in t.shape]
-    nv, nf, regions = _first_call(capi, t, thresh, [0.0] * 3, up)
+    # the mesh's size and the region totals from the count-only pass (no scratch whose regions an uneven field could overflow)
+    ws0 = torch.empty(capi.workspace_bytes(*t.shape), dtype=torch.uint8, device=gpu)
+    capi.count(t, thresh, ws0)
+    nv, nf, fl0, regions = capi.read_counts_ex(ws0)
+    assert fl0 == 0 and sum(regions) == nv, (fl0, nv, sum(regions))
+    if os.environ.get("DEBUG_FIRST"):   # what a scratch-mode call sized 2 x voxels reports on the same field
+        capv = max(4096, 2 * t.numel())
+        v = torch.empty((capv, 3), device=gpu); f = torch.empty((2 * capv, 3), dtype=torch.int32, device=gpu)
+        capi.extract_fused_raw(t, thresh, [0.0] * 3, up, ws0, v, f)
+        r = capi.read_counts_ex(ws0)
+        if r[2] or sum(r[3]) != r[0]:
+            print("scratch-mode call:", tuple(t.shape), "V", r[0], "capv", capv, "flags", r[2], "region max", max(r[3]), "sum", sum(r[3]))
     mode = int(rng.integers(0, 4))
     err = {0: 0.0, 1: 0.02, 2: 0.3, 3: 1.0}[mode]   # exact / a slowly changing field / a different one / anything
     extra = [int(round(r * err * rng.uniform(-1, 1))) for r in regions]

@@ -1,1 +1,1 @@
-for i in 1 2 3 4; do for L in build_dev/lds_tab.so primitive3d_amd/libp3dmc.so; do echo "== $L"; JITS=0,0.01 REPS=1 P3D_CAPI_LIB=$PWD/$L python tools/dev/layout_time.py 2>&1 | tail -3 | cut -c1-200; done; done
+DEBUG_FIRST=1 SEED=23 N=150 python tools/dev/fuzz_parity.py 2>&1 | tail -4
