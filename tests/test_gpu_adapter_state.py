@@ -188,6 +188,30 @@ def test_a_jumping_field_goes_through_the_scratch(gpu, built):
     assert _layout_passes() == l0 + 3   # (all but the first of these: the jumping run ended on b, so that one still saw a, b)
 
 
+def test_the_1024_cubed_volume_laid_out_equals_its_scratch_route(gpu, built):
+    """BASELINE.json's C4 volume on one GPU, the way bench.py's `c4_1gpu` calls it: the third call stores 42 M vertices where they
+    stay (regions of 1.3 M rows each, ids far beyond the 2^26 a region can number on the scratch route).  Same counts as an
+    independent torch count, and the same mesh as the first call's -- vertex for vertex, triangle for triangle (sorted soups)."""
+    from bench import soup_hashes
+    from primitive3d_amd.fields import perlin_grid
+    from tests.test_gpu_configs import torch_counts
+    shape = (1024, 1024, 1024)
+    g = perlin_grid(shape, period=64, seed=0, device=gpu)
+    want = torch_counts(g, 0.0)
+    upper = [float(s_) for s_ in shape]
+    l0 = _layout_passes()
+    v, f = built.libPrim3D.marching_cubes(g, 0.0, [0.0] * 3, upper)
+    assert (v.shape[0], f.shape[0]) == want and _layout_passes() == l0
+    first = soup_hashes(v, f)
+    del v, f
+    built.libPrim3D.marching_cubes(g, 0.0, [0.0] * 3, upper)
+    v, f = built.libPrim3D.marching_cubes(g, 0.0, [0.0] * 3, upper)
+    assert (v.shape[0], f.shape[0]) == want and _layout_passes() == l0 + 1
+    assert int(f.max()) == v.shape[0] - 1 and int(f.min()) == 0
+    third = soup_hashes(v, f)
+    assert all(torch.equal(a, b) for a, b in zip(first, third))
+
+
 def _hip():
     lib = ctypes.CDLL("libamdhip64.so")
     lib.hipStreamCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
