@@ -188,6 +188,34 @@ def test_a_jumping_field_goes_through_the_scratch(gpu, built):
     assert _layout_passes() == l0 + 3   # (all but the first of these: the jumping run ended on b, so that one still saw a, b)
 
 
+def test_a_field_that_jumps_after_standing_still_overflows_the_spill_areas_once(gpu, built):
+    """a, a, a, then b -- a third denser -- from the fourth call on.  The fourth call is laid out from a's totals (a stood
+    still): b's surplus does not fit into the spill areas (V/8 + 4096 rows), the library flags it (bit 2), the adapter emits
+    the mesh again into exactly sized tensors (a second streaming pass) and sits out two calls on the scratch route before
+    it lays b out from b's totals.  Every call returns the right mesh."""
+    from primitive3d_amd import capi
+    from primitive3d_amd.fields import perlin_grid
+    shape = (100, 136, 192)
+    a = perlin_grid(shape, period=32, seed=15, device=gpu)
+    b = perlin_grid(shape, period=16, seed=16, device=gpu)
+    upper = [float(s_) for s_ in shape]
+    wa, wb = capi.extract(a, 0.0, [0.0] * 3, upper), capi.extract(b, 0.0, [0.0] * 3, upper)
+    assert wb[0].shape[0] > 1.3 * wa[0].shape[0]
+    seen = []
+    for i, (g, want) in enumerate([(a, wa)] * 3 + [(b, wb)] * 5):
+        l0, s0 = _layout_passes(), capi.debug_counters()["streaming_launches"]
+        v, f = built.libPrim3D.marching_cubes(g, 0.0, [0.0] * 3, upper)
+        seen.append((_layout_passes() - l0, capi.debug_counters()["streaming_launches"] - s0))
+        assert (v.shape[0], f.shape[0]) == (want[0].shape[0], want[1].shape[0]) and _same_mesh((v, f), want[:2]), i
+        if i == 3:   # (the re-emission: exactly sized, freshly allocated tensors)
+            assert v.untyped_storage().nbytes() == v.shape[0] * 12 and f.untyped_storage().nbytes() == f.shape[0] * 12
+    # (laid out?, launches of the streaming kernel)
+    assert seen[0] in ((0, 1), (0, 2)) and seen[1:3] == [(0, 1), (1, 1)], seen
+    assert seen[3] == (1, 2), seen                      # laid out from a's totals, overflowed, streamed again by p3d_mc_emit
+    assert seen[4:6] == [(0, 1), (0, 1)], seen          # two calls through the scratch
+    assert seen[6:] == [(1, 1), (1, 1)], seen           # b stands still: laid out from b's totals
+
+
 def test_the_1024_cubed_volume_laid_out_equals_its_scratch_route(gpu, built):
     """BASELINE.json's C4 volume on one GPU, the way bench.py's `c4_1gpu` calls it: the third call stores 42 M vertices where they
     stay (regions of 1.3 M rows each, ids far beyond the 2^26 a region can number on the scratch route).  Same counts as an
