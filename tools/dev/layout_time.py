@@ -33,6 +33,8 @@ def call_layout():
         reg = [max(0, int(r * (1 + JIT * (2 * rng.random() - 1)))) for r in reg]
     first, rows = capi.region_layout(reg)
     v = torch.empty((rows, 3), device="cuda")
+    if os.environ.get("ALT") == "1":   # the caller still holds the last mesh: the allocator hands out two blocks in turn
+        state["keep"] = v
     slab = capi.Slab(); slab.region_first_rows = ctypes.cast(first, ctypes.c_void_p)
     capi.extract_fused_raw(g, 0.0, [0, 0, 0], up, ws, v, f, slab=slab)
     nv, nf, fl, reg = capi.read_counts_ex(ws)
