@@ -221,20 +221,25 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
         }
     }
     if (use_layout) {
+        int64_t expect = 0;
+        for (int r = 0; r < 32; ++r) expect += lay_regions[r];
+        const int64_t spill = expect / 8 + 4096;   // the eight areas together
+        use_layout = expect + spill < (int64_t)0x7fff0000;   // (rows are 32-bit in the table; beyond that: the scratch route)
+    }
+    if (use_layout) {
         uint32_t first[41];
         int64_t row = 0;
         for (int r = 0; r < 32; ++r) {
             first[r] = (uint32_t)row;
             row += lay_regions[r];
         }
-        const int64_t spill = row / 8 + 4096;   // the eight areas together
+        const int64_t spill = row / 8 + 4096;
         for (int a = 0; a < 8; ++a) {
             first[32 + a] = (uint32_t)row;
             row += (spill + 7 - a) / 8;
         }
         first[40] = (uint32_t)row;
-        use_layout = row < (int64_t)0x7fff0000;
-        if (use_layout) {
+        {
             const int64_t capv_l = row;
             vertices = torch::empty({capv_l, 3}, vopt);
             if (capf > 0) faces = torch::empty({capf, 3}, fopt);
