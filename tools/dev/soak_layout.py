@@ -14,18 +14,21 @@ rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
 g = perlin_grid(shape, period=32, seed=7, device="cuda", octaves=int(os.environ.get("OCT", "2")), persistence=0.5)
 up = [float(s) for s in shape]
 levels = [-0.06 + 0.003 * k for k in range(41)]
+far = [float(v) for v in os.environ.get("FAR", "").split(",") if v]   # e.g. FAR=-0.4,-0.25,0.25,0.4: levels whose mesh is much
+levels += far                                                        # smaller -- a jump back from one overflows the spill areas
 table = []
 for t in levels:
     v, f = capi.extract(g, t, [0.0] * 3, up)
     table.append((v.shape[0], f.shape[0], soup_hashes(v, f)))
-print("levels:", [(a, b) for a, b, _ in table[::10]])
+print("levels:", [(a, b) for a, b, _ in table[:41:10]], "far:", [(a, b) for a, b, _ in table[41:]])
 k = 20
 c0 = capi.debug_counters()
 checked = 0
 t0 = time.time()
 for i in range(N):
     r = rng.random()
-    if r < 0.04: k = int(rng.integers(0, 41))          # a jump
+    if r < 0.04: k = int(rng.integers(0, len(levels)))          # a jump
+    elif k > 40: pass                                           # (a far level: stay until the next jump)
     elif r < 0.5: k = min(40, k + 1)
     elif r < 0.96: k = max(0, k - 1)
     v, f = p3d.libPrim3D.marching_cubes(g, levels[k], [0.0] * 3, up)
