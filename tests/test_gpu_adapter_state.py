@@ -216,6 +216,42 @@ def test_a_field_that_jumps_after_standing_still_overflows_the_spill_areas_once(
     assert seen[6:] == [(1, 1), (1, 1)], seen           # b stands still: laid out from b's totals
 
 
+def test_threads_sharing_a_shape_share_its_hints(gpu, built):
+    """Three host threads extract three different fields of ONE shape through the adapter (its hints are per shape, process-wide):
+    whatever the interleaving -- a thread's call may be laid out from another thread's field, spill, overflow and be emitted
+    again -- every call returns its own field's mesh."""
+    import threading
+    from primitive3d_amd import capi
+    from primitive3d_amd.fields import perlin_grid
+    shape = (88, 136, 200)
+    upper = [float(s_) for s_ in shape]
+    fields = [perlin_grid(shape, period=32, seed=21, device=gpu), perlin_grid(shape, period=32, seed=22, device=gpu),
+              perlin_grid(shape, period=16, seed=23, device=gpu)]
+    wants = [capi.extract(g, 0.0, [0.0] * 3, upper) for g in fields]
+    torch.cuda.synchronize()
+    errors = []
+    l0 = _layout_passes()
+
+    def work(k):
+        try:
+            with torch.cuda.device(gpu):
+                for i in range(80):
+                    v, f = built.libPrim3D.marching_cubes(fields[k], 0.0, [0.0] * 3, upper)
+                    assert (v.shape[0], f.shape[0]) == (wants[k][0].shape[0], wants[k][1].shape[0]), (k, i)
+                    if i % 16 == 0:
+                        assert _same_mesh((v, f), wants[k][:2]), (k, i)
+        except BaseException as e:   # noqa: BLE001 -- reported by the main thread
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert _layout_passes() > l0   # (runs of one thread's calls in a row do get laid out)
+
+
 def test_the_1024_cubed_volume_laid_out_equals_its_scratch_route(gpu, built):
     """BASELINE.json's C4 volume on one GPU, the way bench.py's `c4_1gpu` calls it: the third call stores 42 M vertices where they
     stay (regions of 1.3 M rows each, ids far beyond the 2^26 a region can number on the scratch route).  Same counts as an
