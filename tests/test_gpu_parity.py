@@ -406,6 +406,7 @@ def test_ply_of_a_device_resident_extraction(gpu, built, tmp_path):
 
 
 @pytest.mark.parametrize("env", [{"P3D_MC_MODE": "exact"}, {"P3D_MC_MODE": "hinted"}, {"P3D_MC_MODE": "scratch"}, {},
+                                 {"P3D_NO_MAILBOX": "1"},   # (the totals and the region totals by copy + synchronise)
                                  {"P3D_MC_MODE": "fast"}])
 def test_adapter_modes_in_a_fresh_process(gpu, env):
     """The pybind adapter's one switch is read once per process: `P3D_MC_MODE=exact` (the reference's own order: count,
