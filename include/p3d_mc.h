@@ -122,7 +122,7 @@ typedef struct p3d_mc_slab {
                                     less on the stream per extraction */
     int32_t reserved;            /* 0 */
     const uint32_t* region_first_rows; /* part 0 without a halo plane only (ABI v10), optional HOST pointer to 41 ascending row
-                                    numbers, [0] = 0, [40] <= cap_vertices: a PREDICTED LAYOUT of the streaming kernel's 32
+                                    numbers, [0] = 0, [40] <= cap_vertices, at most 2^28 rows between two of them: a PREDICTED LAYOUT of the streaming kernel's 32
                                     output regions inside `vertices`.  Region r owns rows [ [r], [r+1] ): give it the rows it
                                     NEEDED in the last call on the shape (p3d_mc_read_counts_ex reports the 32 totals), without
                                     slack; behind the regions, [ [32+g], [33+g] ) is spill area g (g < 8: what the regions

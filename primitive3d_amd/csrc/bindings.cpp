@@ -225,6 +225,8 @@ std::vector<Tensor> marching_cubes(const Tensor& density_grid, const float thres
         for (int r = 0; r < 32; ++r) expect += lay_regions[r];
         const int64_t spill = expect / 8 + 4096;   // the eight areas together
         use_layout = expect + spill < (int64_t)0x7fff0000;   // (rows are 32-bit in the table; beyond that: the scratch route)
+        for (int r = 0; r < 32; ++r) use_layout = use_layout && lay_regions[r] <= (int64_t(1) << 28);   // (the library's limit per region)
+        use_layout = use_layout && spill / 8 < (int64_t(1) << 28);
     }
     if (use_layout) {
         uint32_t first[41];

@@ -2303,6 +2303,10 @@ int fused_impl(const T* grid, const Dims& d, const Ws& w, float thresh, const Xf
         bool ok = lay_v.first[0] == 0u && (int64_t)lay_v.first[kLayRows - 1] <= capv && lay_v.first[kLayRows - 1] < 0x7fffff00u;
         for (int r = 0; r + 1 < kLayRows; ++r) ok = ok && lay_v.first[r] <= lay_v.first[r + 1];
         if (!ok) return fail(P3D_EINVAL, "region_first_rows must be 41 ascending rows from 0 to at most cap_vertices%s");
+        // (the streaming kernel addresses a row by a 32-bit byte offset from its region's or spill area's first row)
+        for (int r = 0; r + 1 < kLayRows; ++r)
+            if (lay_v.first[r + 1] - lay_v.first[r] > kLayMaxRows)
+                return fail(P3D_EINVAL, "region_first_rows: a region or spill area may hold at most 2^28 rows%s");
         lay_v.on = 1u;
         lay = &lay_v;
     }

@@ -151,3 +151,11 @@ def test_bad_layouts_are_refused(gpu):
         slab.region_first_rows = ctypes.cast(arr, ctypes.c_void_p)
         with pytest.raises(capi.P3DError, match="region_first_rows"):
             capi.extract_fused_raw(g, 0.5, [0.0] * 3, [1.0] * 3, ws, v, f, slab=slab)
+    # a region of more than 2^28 rows (the kernel addresses a row by a 32-bit byte offset from its region's first row)
+    big = torch.empty(((1 << 28) + 4096, 3), device=gpu)   # (3.2 GB: the table must fit into the buffer to get that far)
+    rows = [0] + [(1 << 28) + 1 + 8 * r for r in range(40)]
+    slab = capi.Slab()
+    arr = (ctypes.c_uint32 * 41)(*rows)
+    slab.region_first_rows = ctypes.cast(arr, ctypes.c_void_p)
+    with pytest.raises(capi.P3DError, match="2\\^28 rows"):
+        capi.extract_fused_raw(g, 0.5, [0.0] * 3, [1.0] * 3, ws, big, f, slab=slab)
