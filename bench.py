@@ -359,6 +359,9 @@ def run_child(cmd, timeout, capture=False, **kw):
         raise
 
 
+CALL_KERNELS = ("k_fused<", "k_face_count_walk<", "k_faces<")   # the three launches of a whole-grid call
+
+
 def measure_traffic_live():
     """The bytes `k_fused` moves over the fabric per launch, measured in THIS run: two `rocprofv3 --pmc` passes (counters
     only, with --kernel-trace: the combination the GPU pool allows) over a child process that makes the headline's call
@@ -384,15 +387,26 @@ def measure_traffic_live():
                 acc = {}
                 for f in glob.glob(f"{td}/{tag}/**/*counter_collection.csv", recursive=True):
                     for r in csv.DictReader(open(f)):
-                        if "k_fused" in r["Kernel_Name"]:
-                            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                        for kern in CALL_KERNELS:
+                            if kern in r["Kernel_Name"]:
+                                acc.setdefault((kern, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
                 for c, v in acc.items():
                     got[c] = sum(v[-3:]) / len(v[-3:])
-        rd = 32 * got["TCC_EA0_RDREQ_32B_sum"] + 64 * got["TCC_EA0_RDREQ_64B_sum"] + 128 * got["TCC_EA0_RDREQ_128B_sum"]
-        wr = 1024 * got["WRITE_SIZE"]
+
+        def read_of(kern):
+            return (32 * got[(kern, "TCC_EA0_RDREQ_32B_sum")] + 64 * got[(kern, "TCC_EA0_RDREQ_64B_sum")]
+                    + 128 * got[(kern, "TCC_EA0_RDREQ_128B_sum")])
+
+        rd, wr = read_of("k_fused<"), 1024 * got[("k_fused<", "WRITE_SIZE")]
         if rd <= 0 or wr <= 0:
             return None
-        return {"read": int(rd), "write": int(wr)}
+        out = {"read": int(rd), "write": int(wr)}
+        try:   # the whole call: the streaming kernel, the triangle count, the faces (the last three calls of the child)
+            out["call_read"] = int(sum(read_of(k) for k in CALL_KERNELS))
+            out["call_write"] = int(sum(1024 * got[(k, "WRITE_SIZE")] for k in CALL_KERNELS))
+        except KeyError:
+            pass
+        return out
     except Exception:
         return None
 
@@ -772,6 +786,11 @@ def main():
             roofline["traffic_frac"] = round(roofline["traffic"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             if live:
                 roofline["traffic_read"], roofline["traffic_write"] = live["read"], live["write"]
+                if "call_read" in live:
+                    # the WHOLE call over the fabric (all three kernels), and the rate the call reaches on those bytes
+                    roofline["call_traffic_read"], roofline["call_traffic_write"] = live["call_read"], live["call_write"]
+                    roofline["call_traffic"] = live["call_read"] + live["call_write"]
+                    roofline["call_traffic_frac"] = round(roofline["call_traffic"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                 roofline["traffic_source"] = ("this run: rocprofv3 --pmc over a child making the same call (fabric read requests by "
                                               "request size; WRITE_SIZE), k_fused, mean of the last 3 of 7 launches")
                 roofline.pop("traffic_build", None)

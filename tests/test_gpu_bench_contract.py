@@ -109,5 +109,10 @@ def test_default_run_reports_the_other_configs(gpu):
         #  twice; the vertex rows are written at least once)
         assert 0.9 * r["alg_bytes_per_launch"] <= r["traffic_read"] < 2.0 * r["alg_bytes_per_launch"]
         assert 12 * d["config"]["vertices"] <= r["traffic_write"] < 4 * 12 * d["config"]["vertices"]
+        # the whole call over the fabric (all three kernels): at least what it must read and write -- the field, V rows, F rows
+        # -- and (every vertex row stored once in the steady state) well under the 1.06 GB it took through the scratch
+        must = r["alg_bytes_per_launch"] + 12 * d["config"]["vertices"] + 12 * d["config"]["faces"]
+        assert r["call_traffic"] == r["call_traffic_read"] + r["call_traffic_write"] and must <= r["call_traffic"] < 1.0e9
+        assert r["traffic"] < r["call_traffic"] and 0 < r["call_traffic_frac"] < 1.0
     else:
         assert r["traffic_build"]
